@@ -1,0 +1,81 @@
+"""ctypes binding of libbas_hip.so (the C ABI declared in include/bas.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception
+is raised.  Device memory, streams and process groups come from PyTorch-ROCm; the
+arithmetic is entirely in the HIP library.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbas_hip.so")
+
+_c_int, _c_long, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/bas.h
+SIGNATURES = {
+    "bas_version": (_c_int, []),
+    "bas_last_error": (ctypes.c_char_p, []),
+    "bas_table_pack_f32": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "bas_delay_signal_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "bas_ring_interp_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                     _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "bas_interp2d_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
+                                  _c_int, _c_void_p, _c_void_p]),
+    "bas_render_workspace_bytes": (_c_size_t, [_c_int, _c_long, _c_int, _c_int, _c_int]),
+    "bas_render_mix_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_int,
+                                    _c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "bas_peak_normalize_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_void_p]),
+    "bas_scale_by_peak_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
+}
+
+_lib = None
+
+
+class BasError(RuntimeError):
+    def __init__(self, fn, code, text):
+        super().__init__(f"{fn} failed with code {code}: {text}")
+        self.code = code
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"or `make -C {os.path.dirname(LIB_PATH)}`.  There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if handle.bas_version() != 1:
+            raise RuntimeError(f"libbas_hip.so ABI version {handle.bas_version()} != 1")
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise BasError on a non-zero code."""
+    l = lib()
+    rc = getattr(l, name)(*args)
+    if rc != 0:
+        raise BasError(name, rc, l.bas_last_error().decode(errors="replace"))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(device=None):
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no MI355X visible to PyTorch-ROCm: this renderer has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

@@ -1,0 +1,263 @@
+"""Host side of the MI355X renderer: the reference's apply_hrtf.py interface for the
+path load_irs_and_delaydiffs -> interpolate_2d -> make_signal_move_2d.
+
+Same function names, argument meaning and error behaviour as the reference
+(file:line citations below are into the reference's apply_hrtf.py); audio, table
+and parameters live in HBM as PyTorch-ROCm tensors and every arithmetic step is a
+call into libbas_hip.so (include/bas.h).  There is no CPU fallback.
+
+Differences a caller can see (all documented in DESIGN.md):
+  * results are float32 end to end (the reference computes in float64 and casts
+    the render to float32 at :459); parity bound 1e-5 norm-relative.
+  * progress printing (:456-457) is off unless verbose=True.
+  * batched forms (`interpolate_2d_batch`, `render_sources`) exist for many
+    queries / many sources; the reference has none.
+"""
+import math
+
+import numpy as np
+
+from . import _hip
+from . import sphere
+
+
+# --------------------------------------------------------------------------
+# a1: the table
+# --------------------------------------------------------------------------
+class irs_and_delaydiffs:
+    """Device-resident table with the five attributes of the reference's struct
+    (apply_hrtf.py:36-44) plus the packed forms the kernels read."""
+
+    def __init__(self, upsampling, diffs_left, diffs_right, irs_left, irs_right, device=None):
+        import torch
+        device = _hip.require_gpu(device)
+        self.upsampling = int(upsampling)                                   # :38
+        il = np.ascontiguousarray(irs_left, dtype=np.float32)
+        ir = np.ascontiguousarray(irs_right, dtype=np.float32)
+        dl = np.ascontiguousarray(diffs_left, dtype=np.float64)
+        dr = np.ascontiguousarray(diffs_right, dtype=np.float64)
+        if il.shape != ir.shape or il.ndim != 2 or il.shape[1] % self.upsampling:
+            raise ValueError("irs_left/irs_right must be (ndir, samples_to_keep*upsampling)")
+        n = il.shape[0]
+        if dl.shape != (n, n) or dr.shape != (n, n):
+            raise ValueError("diffs_left/diffs_right must be (ndir, ndir)")
+        self.device = device
+        self.ndir, self.M = il.shape
+        self.L = self.M // self.upsampling
+        irs = torch.from_numpy(np.stack([il, ir])).to(device)               # [2][ndir][M]
+        self.irs_left, self.irs_right = irs[0], irs[1]                      # :43-44
+        self.diffs = torch.from_numpy(np.stack([dl, dr])).to(device)        # [2][ndir][ndir] f64
+        self.diffs_left, self.diffs_right = self.diffs[0], self.diffs[1]    # :40-41
+        self.packed = torch.empty_like(irs)                                 # [2][ndir][U][L]
+        _hip.call("bas_table_pack_f32", _hip.ptr(irs), self.ndir, self.M, self.upsampling,
+                  _hip.ptr(self.packed), _hip.current_stream(device))
+
+
+def load_irs_and_delaydiffs(filename='irs_and_delaydiffs_compensated_6.mat', samples_to_keep=512, device=None):
+    """Load the table written by upsample_irs.m and keep the first
+    samples_to_keep*upsampling columns of every IR (apply_hrtf.py:23-46)."""
+    import scipy.io
+    m = scipy.io.loadmat(filename)['irs_and_delaydiffs']                    # :34
+    rec = m[0][0]
+    upsampling = int(rec['upsampling'][0][0])                               # :38
+    keep = samples_to_keep * upsampling
+    return irs_and_delaydiffs(upsampling, rec['diffs_left'], rec['diffs_right'],
+                              rec['irs_left'][:, :keep], rec['irs_right'][:, :keep], device=device)
+
+
+def as_device_table(tbl, device=None):
+    """Accept this module's table, or any object with the reference's five attributes
+    holding numpy arrays (e.g. the reference's own class-as-struct); the device copy
+    is cached on the object."""
+    if isinstance(tbl, irs_and_delaydiffs):
+        return tbl
+    cached = getattr(tbl, "_bas_device_table", None)
+    if cached is None:
+        cached = irs_and_delaydiffs(tbl.upsampling, tbl.diffs_left, tbl.diffs_right,
+                                    tbl.irs_left, tbl.irs_right, device=device)
+        try:
+            tbl._bas_device_table = cached
+        except (AttributeError, TypeError):
+            pass
+    return cached
+
+
+# --------------------------------------------------------------------------
+# a4 / a5
+# --------------------------------------------------------------------------
+def delay_signal_float(in_sig, samples, downsample=1):
+    """Fractional circular delay by linear blend of the two adjacent integer shifts
+    (apply_hrtf.py:127-165).  in_sig: 1-D array; returns a float32 numpy array."""
+    import torch
+    device = _hip.require_gpu()
+    x = torch.as_tensor(np.ascontiguousarray(in_sig, dtype=np.float32)).reshape(1, -1).to(device)
+    m = x.shape[1]
+    s = torch.tensor([float(samples)], dtype=torch.float64, device=device)
+    y = torch.empty((1, (m + downsample - 1) // downsample), dtype=torch.float32, device=device)
+    _hip.call("bas_delay_signal_f32", _hip.ptr(x), _hip.ptr(s), 1, m, int(downsample), _hip.ptr(y),
+              _hip.current_stream(device))
+    return y[0].cpu().numpy()
+
+
+def delay_compensated_interpolation_with_delaydiff(irs_and_delaydiffs, before: int, after: int, alpha: float,
+                                                   return_upsampled=False):
+    """Delay-compensated interpolation along one ring, both ears (apply_hrtf.py:53-106).
+    Returns (delay_l, delay_r, irs[2, M or L])."""
+    import torch
+    tbl = as_device_table(irs_and_delaydiffs)
+    dev = tbl.device
+    if not (0 <= int(before) < tbl.ndir and 0 <= int(after) < tbl.ndir):
+        raise IndexError("HRTF database index out of range")
+    pq = torch.tensor([[int(before), int(after)]], dtype=torch.int32, device=dev)
+    al = torch.tensor([float(alpha)], dtype=torch.float64, device=dev)
+    width = tbl.M if return_upsampled else tbl.L
+    out = torch.empty((1, 2, width), dtype=torch.float32, device=dev)
+    delays = torch.empty((1, 2), dtype=torch.float64, device=dev)
+    _hip.call("bas_ring_interp_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(pq), _hip.ptr(al), 1,
+              tbl.ndir, tbl.L, tbl.upsampling, int(bool(return_upsampled)), _hip.ptr(out), _hip.ptr(delays),
+              _hip.current_stream(dev))
+    d = delays.cpu().numpy()
+    return (d[0, 0], d[0, 1], out[0].cpu().numpy())
+
+
+# --------------------------------------------------------------------------
+# a6
+# --------------------------------------------------------------------------
+def interpolate_2d_params(tbl, idx, w):
+    """Batched table arithmetic of interpolate_2d (apply_hrtf.py:219-279) for
+    precomputed parameters: idx int32 [n,4], w float64 [n,3] (numpy or device
+    tensors).  Returns a device tensor [n, 2, L] float32."""
+    import torch
+    tbl = as_device_table(tbl)
+    dev = tbl.device
+    idx_t = torch.as_tensor(idx, dtype=torch.int32).reshape(-1, 4).contiguous().to(dev)
+    w_t = torch.as_tensor(w, dtype=torch.float64).reshape(-1, 3).contiguous().to(dev)
+    n = idx_t.shape[0]
+    if w_t.shape[0] != n:
+        raise ValueError("idx and w disagree on the number of queries")
+    if n and (int(idx_t.min()) < 0 or int(idx_t.max()) >= tbl.ndir):
+        raise IndexError("HRTF database index out of range")
+    H = torch.empty((n, 2, tbl.L), dtype=torch.float32, device=dev)
+    _hip.call("bas_interp2d_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(idx_t), _hip.ptr(w_t), n,
+              tbl.ndir, tbl.L, tbl.upsampling, _hip.ptr(H), _hip.current_stream(dev))
+    return H
+
+
+def interpolate_2d_batch(tbl, elev, azim):
+    """interpolate_2d for float64 arrays of angles (radians); device tensor [..., 2, L]."""
+    idx, w = sphere.interpolation_params_batch(elev, azim)
+    H = interpolate_2d_params(tbl, idx.reshape(-1, 4), w.reshape(-1, 3))
+    return H.reshape(idx.shape[:-1] + (2, H.shape[-1]))
+
+
+def interpolate_2d(irs_and_delaydiffs, elev, azim):
+    """HRIR pair for a source at (elev, azim) radians (apply_hrtf.py:171-281).
+    Returns a (2, L) float32 numpy array.  Elevation outside [-pi/4, pi/2] is clamped,
+    azimuth is wrapped, like the reference."""
+    idx, w = sphere.interpolation_params(elev, azim)
+    H = interpolate_2d_params(irs_and_delaydiffs, np.array([idx], dtype=np.int32), np.array([w]))
+    return H[0].cpu().numpy()
+
+
+def interpolate_2d_deg(irs_and_delaydiffs, elev, azim):
+    deg2rad = (2 * np.pi) / 360                                             # :167-169
+    return interpolate_2d(irs_and_delaydiffs, deg2rad * elev, deg2rad * azim)
+
+
+# --------------------------------------------------------------------------
+# a7
+# --------------------------------------------------------------------------
+def render_lengths(n, chunksize, ir_length):
+    in_length = int(0.5 + math.ceil(n / chunksize) * chunksize)             # :405
+    return in_length, in_length + ir_length - 1                             # :410
+
+
+def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=None, accumulate=False):
+    """Core launch: x [n_src, T_in] device float32 (T_in % K == 0), H [n_src, n_chunks+1, 2, L].
+    Returns (y [2, T_out] device float32, peak device scalar)."""
+    import torch
+    dev = x.device
+    n_src, t_in = x.shape
+    t_out = t_in + tbl_L - 1
+    y = out if out is not None else torch.empty((2, t_out), dtype=torch.float32, device=dev)
+    peak = torch.empty((1,), dtype=torch.float32, device=dev)
+    ws_bytes = _hip.lib().bas_render_workspace_bytes(n_src, t_in, chunksize, subchunksize, tbl_L)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    stream = _hip.current_stream(dev)
+    _hip.call("bas_render_mix_f32", _hip.ptr(x), x.stride(0) if n_src else t_in, _hip.ptr(H), n_src, t_in,
+              chunksize, subchunksize, tbl_L, _hip.ptr(y), int(bool(accumulate)), _hip.ptr(peak), _hip.ptr(ws),
+              ws_bytes, stream)
+    if normalize == "mix":
+        _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(peak), stream)   # :462-464
+    elif normalize != "none":
+        raise ValueError("normalize must be 'mix' or 'none'")
+    return y, peak
+
+
+def render_sources(signals, chunksize, subchunksize, elev, azim, tbl, normalize="mix"):
+    """Render and mix many independently moving sources.
+
+    signals: [n_src, N] (numpy or tensor); elev/azim: float64 [n_src, n_chunks+1]
+    radians at t = 0, K, .., in_length (what make_signal_move_2d samples, :429/:435).
+    Mix semantics (not defined by the reference): sum of the un-normalised
+    renders, then the reference's peak rule once on the mix ("mix") or not at all
+    ("none").  Returns a device tensor of shape (out_length, 2) - a transposed view of
+    [2, out_length], the same memory order the reference returns (:459).
+    """
+    import torch
+    tbl = as_device_table(tbl)
+    dev = tbl.device
+    assert chunksize % subchunksize == 0, 'subchunksize does not divide chunksize evenly'
+    sig = torch.as_tensor(signals)
+    assert sig.dim() == 2, 'signals must be [n_src, N]'
+    n_src, n = sig.shape
+    in_length, _ = render_lengths(n, chunksize, tbl.L)
+    x = torch.zeros((n_src, in_length), dtype=torch.float32, device=dev)    # :406
+    x[:, :n] = sig.to(device=dev, dtype=torch.float32)
+    n_q = in_length // chunksize + 1
+    idx, w = sphere.interpolation_params_batch(elev, azim)
+    if idx.shape[:-1] != (n_src, n_q):
+        raise ValueError(f"elev/azim must have shape ({n_src}, {n_q})")
+    H = interpolate_2d_params(tbl, idx.reshape(-1, 4), w.reshape(-1, 3)).reshape(n_src, n_q, 2, tbl.L)
+    y, _ = render_device(x, chunksize, subchunksize, H, tbl.L, normalize)
+    return y.t()
+
+
+def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_function, irs_and_delaydiffs,
+                        verbose=False):
+    """Make `in_signal` sound as if its source moved along elev_azim_function
+    (apply_hrtf.py:356-466): chunk IRs by interpolate_2d at t = 0, K, .., in_length,
+    per-subchunk linear IR crossfade, direct FIR, overlap-add, float32, peak rule.
+
+    in_signal: 1-D numpy array (returns numpy (out_length, 2) float32, :459) or 1-D
+    device tensor (returns a device tensor of that shape).
+    elev_azim_function(t_samples) -> (elev, azim) in radians; it is called with the
+    same scalar arguments as the reference calls it, so grid-node decisions follow the
+    dtype it returns exactly as in the reference (sphere.py).
+    """
+    import torch
+    is_tensor = isinstance(in_signal, torch.Tensor)
+    assert len(in_signal.shape) == 1, 'only mono signals for now'            # :398
+    chunks_per_subchunk = chunksize / subchunksize
+    assert chunks_per_subchunk == np.floor(chunks_per_subchunk), 'subchunksize does not divide chunksize evenly'
+    tbl = as_device_table(irs_and_delaydiffs)
+    dev = tbl.device
+    n = int(in_signal.shape[0])
+    in_length, out_length = render_lengths(n, chunksize, tbl.L)
+    times = range(0, in_length + 1, chunksize)                               # :429, :435
+    idx = np.empty((len(times), 4), dtype=np.int32)
+    w = np.empty((len(times), 3), dtype=np.float64)
+    for i, t in enumerate(times):
+        idx[i], w[i] = sphere.interpolation_params(*elev_azim_function(t))
+        if verbose:
+            print(' {:.1f}%           '.format(100 * t / max(in_length, 1)), end='\r')
+    x = torch.zeros((1, in_length), dtype=torch.float32, device=dev)         # :405-406
+    src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
+    x[0, :n] = src.to(device=dev, dtype=torch.float32)
+    H = interpolate_2d_params(tbl, idx, w).reshape(1, len(times), 2, tbl.L)
+    y, _ = render_device(x, int(chunksize), int(subchunksize), H, tbl.L, "mix")
+    if verbose:
+        print(' 100.0%      ')
+    out = y.t()                                                              # (out_length, 2), F-ordered like :459
+    assert out.shape[0] == out_length, 'wrong output length'
+    return out if is_tensor else out.cpu().numpy()

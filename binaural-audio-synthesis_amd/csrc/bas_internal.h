@@ -1,0 +1,37 @@
+// Internal helpers shared by the translation units of libbas_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/bas.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// thread-local last-error text (bas_abi.hip)
+void bas_set_error(const char *fmt, ...);
+int bas_fail(int code, const char *fmt, ...);
+int bas_check_launch(const char *what);
+
+static inline hipStream_t bas_stream(bas_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define BAS_REQUIRE(cond, code, ...) \
+    do { if (!(cond)) return bas_fail((code), __VA_ARGS__); } while (0)
+
+// non-negative remainder for any int c and M > 0
+__device__ __forceinline__ int bas_pmod(long long c, int M) {
+    long long r = c % (long long)M;
+    return (int)(r < 0 ? r + M : r);
+}
+
+// s = b + f with b = floor(s) (saturated to a range whose sums cannot overflow), f in [0,1)
+__device__ __forceinline__ void bas_split_shift(double s, long long &b, float &f) {
+    if (!(s == s)) s = 0.0;                       // NaN shift: treat as 0 (reference would raise)
+    if (s > 1e15) s = 1e15;
+    if (s < -1e15) s = -1e15;
+    double fl = floor(s);
+    b = (long long)fl;
+    f = (float)(s - fl);
+}

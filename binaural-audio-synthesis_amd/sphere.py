@@ -1,0 +1,159 @@
+"""Sphere geometry of the 187-direction HRIR grid and the angle -> (indices, weights) step.
+
+Mirrors the part of the reference's sphere.py that is on the render path:
+the module constant `index_elev_azim` (sphere.py:124-319, :350) and
+`azim_to_interpolation_params` (sphere.py:78-121), plus a vectorised float64 form
+that also does interpolate_2d's elevation bracket (apply_hrtf.py:199-215, :261-266)
+for whole trajectories at once.
+
+Branch decisions at grid nodes are parity critical (the interpolation jumps by
+~1e-2 of the IR peak across a node): node angles are float32
+values float32(deg) * float32(2*pi/360) exactly as the reference builds them, and
+the scalar function keeps numpy's promotion rules (a Python-float azimuth is
+handled in float32, an np.float64 azimuth in float64).  The vectorised form
+implements the np.float64 branch.
+"""
+import numpy as np
+
+RING_ELEVS_DEG = (-45, -30, -15, 0, 15, 30, 45, 60, 75, 90)
+RING_COUNTS = (24, 24, 24, 24, 24, 24, 24, 12, 6, 1)
+RING_START = tuple(int(v) for v in np.concatenate([[0], np.cumsum(RING_COUNTS)[:-1]]))
+N_DIRECTIONS = 187
+POLE = 186
+_TOL = 0.00001                                      # sphere.py:90
+
+
+def get_index_elev_azim():
+    """(187,3) float32 [index, elev_rad, azim_rad] (sphere.py:124-319)."""
+    t = np.empty((N_DIRECTIONS, 3), dtype=np.float32)
+    row = 0
+    for elev, count in zip(RING_ELEVS_DEG, RING_COUNTS):
+        step = 360 // count
+        for i in range(count):
+            t[row] = (row, elev, i * step)
+            row += 1
+    t[:, 1:3] *= (2 * np.pi / 360)                  # in-place float32 scaling, sphere.py:318
+    return t
+
+
+index_elev_azim = get_index_elev_azim()             # sphere.py:350
+_RING_ELEV32 = np.array([index_elev_azim[s, 1] for s in RING_START], dtype=np.float32)
+_AVAILABLE_ELEVS = np.deg2rad(np.array(RING_ELEVS_DEG))          # apply_hrtf.py:199 (float64)
+
+
+def azim_to_interpolation_params(elev, azim):
+    """(before, a, after) on the database ring at `elev` (sphere.py:78-121).
+
+    `elev` must be a database elevation (ValueError otherwise, sphere.py:100-101);
+    out-of-range elevations are clamped (:88), azimuth is wrapped (:86).
+    """
+    azim = azim % (2 * np.pi)
+    assert azim >= 0
+    elev = np.clip(elev, -np.pi / 4, np.pi / 2)
+    if abs(elev - np.pi / 2) < _TOL:
+        return (POLE, 0., POLE)
+    hit = np.nonzero(np.abs(_RING_ELEV32 - elev) < _TOL)[0]
+    if hit.size == 0:
+        raise ValueError('ele must be one of the values in the database: '
+                         '[-45,-30,-15,0,15,30,45,60,75,90] .* (2pi / 360)')
+    start, count = RING_START[hit[0]], RING_COUNTS[hit[0]]
+    nodes = index_elev_azim[start:start + count, 2]
+    n_le = int(np.count_nonzero(nodes <= azim))     # nodes ascend, node 0 is azimuth 0
+    before = start + n_le - 1
+    after = start + n_le if n_le < count else start
+    before_azim = index_elev_azim[before, 2]
+    after_azim = index_elev_azim[after, 2]
+    if after_azim < before_azim:
+        after_azim = 2 * np.pi
+    a = (azim - before_azim) / (after_azim - before_azim)
+    return (before, a, after)
+
+
+def elevation_bracket(elev):
+    """(lower, higher) database elevations around elev, clamped (apply_hrtf.py:201-211)."""
+    le = _AVAILABLE_ELEVS[_AVAILABLE_ELEVS <= elev]
+    ge = _AVAILABLE_ELEVS[_AVAILABLE_ELEVS >= elev]
+    lower = le.max() if le.size else -0.78539816339744828
+    higher = ge.min() if ge.size else 1.5707963267948966
+    assert higher >= lower, "something's messed up"
+    return lower, higher
+
+
+def interpolation_params(elev, azim):
+    """Scalar form of everything interpolate_2d derives from the angles:
+    (top_before, top_after, bot_before, bot_after), (top_alpha, bot_alpha, a)."""
+    lower, higher = elevation_bracket(elev)
+    tb, ta, taf = azim_to_interpolation_params(higher, azim)      # apply_hrtf.py:214
+    bb, ba, baf = azim_to_interpolation_params(lower, azim)       # :215
+    if higher > lower:                                            # :261-266
+        a = (elev - lower) / (higher - lower)
+    else:
+        a = 0
+    assert 0 <= a <= 1, 'interpolation parameter somehow takes invalid value'
+    return (tb, taf, bb, baf), (float(ta), float(ba), float(a))
+
+
+# ---------------------------------------------------------------------------
+# vectorised float64 form (np.float64 branch), for whole trajectories
+# ---------------------------------------------------------------------------
+_NODES64 = [index_elev_azim[s:s + c, 2].astype(np.float64) for s, c in zip(RING_START, RING_COUNTS)]
+_NODES32 = [index_elev_azim[s:s + c, 2] for s, c in zip(RING_START, RING_COUNTS)]
+
+
+def _ring_params_batch(ring, azim_mod):
+    """before, after (int32) and a (float64) for ring indices `ring` (0..9) and wrapped azimuths."""
+    n = azim_mod.shape[0]
+    before = np.empty(n, dtype=np.int32)
+    after = np.empty(n, dtype=np.int32)
+    a = np.empty(n, dtype=np.float64)
+    for r in range(10):
+        sel = np.nonzero(ring == r)[0]
+        if sel.size == 0:
+            continue
+        if r == 9:                                  # pole: sphere.py:92-93
+            before[sel] = POLE
+            after[sel] = POLE
+            a[sel] = 0.0
+            continue
+        az = azim_mod[sel]
+        start, count = RING_START[r], RING_COUNTS[r]
+        j = np.searchsorted(_NODES64[r], az, side="right") - 1     # last node <= azim (float64 compare)
+        wrap = j + 1 >= count
+        ja = np.where(wrap, 0, j + 1)
+        b32 = _NODES32[r][j]
+        a32 = np.where(wrap, np.float32(2 * np.pi), _NODES32[r][ja]).astype(np.float32)
+        denom = (a32 - b32).astype(np.float64)      # float32 subtraction, as sphere.py:119 evaluates it
+        before[sel] = start + j
+        after[sel] = start + ja
+        a[sel] = (az - b32.astype(np.float64)) / denom
+    return before, a, after
+
+
+def interpolation_params_batch(elev, azim):
+    """Vectorised interpolation_params for float64 arrays of any (equal) shape.
+
+    Returns idx int32 [..., 4] = (top_before, top_after, bot_before, bot_after) and
+    w float64 [..., 3] = (top_alpha, bot_alpha, a): the inputs of bas_interp2d_f32.
+    """
+    elev = np.asarray(elev, dtype=np.float64)
+    azim = np.asarray(azim, dtype=np.float64)
+    elev, azim = np.broadcast_arrays(elev, azim)
+    shape = elev.shape
+    e = elev.reshape(-1)
+    z = azim.reshape(-1) % (2 * np.pi)
+    if not (np.isfinite(e).all() and np.isfinite(z).all()):
+        raise ValueError("trajectory contains non-finite angles")
+    hi = np.searchsorted(_AVAILABLE_ELEVS, e, side="left")        # first elevation >= elev
+    lo = np.searchsorted(_AVAILABLE_ELEVS, e, side="right") - 1   # last elevation <= elev
+    hi = np.minimum(hi, 9)                                        # above +90: clamp (apply_hrtf.py:206-209)
+    lo = np.maximum(lo, 0)                                        # below -45: clamp (:201-204)
+    lower, higher = _AVAILABLE_ELEVS[lo], _AVAILABLE_ELEVS[hi]
+    tb, ta, taf = _ring_params_batch(hi, z)
+    bb, ba, baf = _ring_params_batch(lo, z)
+    span = higher - lower
+    a = np.where(span > 0, (e - lower) / np.where(span > 0, span, 1.0), 0.0)
+    if ((a < 0) | (a > 1)).any():
+        raise AssertionError('interpolation parameter somehow takes invalid value')
+    idx = np.stack([tb, taf, bb, baf], axis=-1).astype(np.int32).reshape(shape + (4,))
+    w = np.stack([ta, ba, a], axis=-1).reshape(shape + (3,))
+    return idx, w

@@ -1,0 +1,123 @@
+/* bas.h - C ABI of the MI355X (gfx950) binaural render library, libbas_hip.so.
+ *
+ * The reference (mbjd/binaural-audio-synthesis) is pure Python and has no FFI
+ * boundary of its own: its boundary for the moving-source render path is three
+ * Python functions in apply_hrtf.py.  This header is the native boundary this
+ * build puts BEHIND those functions; every entry point names the reference
+ * interface it replaces (file:line into the reference tree).  The ctypes stub a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     marked "host"; nothing here allocates, frees or retains caller memory.
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*; NULL =
+ *     the default stream) and returns without synchronising, so calls can be
+ *     captured into a hipGraph.
+ *   - return value: 0 = ok, negative = BAS_E_* argument/shape error (nothing
+ *     was enqueued), positive = hipError_t reported by the launch.
+ *     bas_last_error() returns a thread-local description of the last failure.
+ *   - re-entrant; no mutable global state besides that thread-local string.
+ *   - float data is IEEE binary32, computed in binary32 on the device ("f32");
+ *     delay bookkeeping (shift amounts) is computed in binary64.
+ */
+#ifndef BAS_H
+#define BAS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BAS_ABI_VERSION 1
+
+#define BAS_E_NULL      (-1)   /* a required pointer is NULL                    */
+#define BAS_E_SHAPE     (-2)   /* inconsistent or unsupported sizes             */
+#define BAS_E_ALIGN     (-3)   /* pointer/stride alignment requirement violated */
+#define BAS_E_WORKSPACE (-4)   /* workspace too small                           */
+
+typedef void *bas_stream_t;    /* hipStream_t */
+
+/* Library / ABI version (BAS_ABI_VERSION). */
+int bas_version(void);
+
+/* Thread-local text for the last non-zero return on this thread ("" if none). */
+const char *bas_last_error(void);
+
+/* ---- a1: table layout ----------------------------------------------------
+ * Replaces the in-memory table produced by load_irs_and_delaydiffs
+ * (apply_hrtf.py:23-46): irs_left/irs_right truncated to M = samples_to_keep*U
+ * columns (:43-44).  Re-lays the row-major table
+ *     irs   [2 ears][ndir][M]            (ear 0 = left)
+ * as phase planes
+ *     packed[2 ears][ndir][U][L],  packed[e][p][i % U][i / U] = irs[e][p][i],
+ * L = M / U, so that the stride-U reads of a fractional shift followed by
+ * decimation (apply_hrtf.py:156-165) are contiguous across lanes. */
+int bas_table_pack_f32(const float *irs, int ndir, int M, int U, float *packed,
+                       bas_stream_t stream);
+
+/* ---- a4: delay_signal_float (apply_hrtf.py:127-165) ------------------------
+ * y[i][j] = (1-f) x[i][(j*down - floor s_i) mod M] + f x[i][(j*down - ceil s_i) mod M],
+ * f = s_i - floor s_i, j = 0..ceil(M/down)-1; circular like np.roll (:156-157);
+ * decimation before the blend (:160-163).
+ *   x [n][M] f32, shifts [n] f64 (samples), y [n][ceil(M/down)] f32. */
+int bas_delay_signal_f32(const float *x, const double *shifts, int n, int M, int down,
+                         float *y, bas_stream_t stream);
+
+/* ---- a5: delay_compensated_interpolation_with_delaydiff (apply_hrtf.py:53-106)
+ *   packed  table from bas_table_pack_f32
+ *   diffs   [2 ears][ndir][ndir] f64   (diffs_left, diffs_right; :40-41)
+ *   pq      [n][2] int32   (before, after)
+ *   alpha   [n] f64
+ *   out     [n][2 ears][return_upsampled ? M : L] f32   (:97-104)
+ *   delays  [n][2 ears] f64, in non-upsampled samples (:106); may be NULL. */
+int bas_ring_interp_f32(const float *packed, const double *diffs, const int32_t *pq,
+                        const double *alpha, int n, int ndir, int L, int U,
+                        int return_upsampled, float *out, double *delays,
+                        bas_stream_t stream);
+
+/* ---- a6: interpolate_2d (apply_hrtf.py:171-281), batched --------------------
+ * The angle -> (indices, weights) step (sphere.py:78-121 and the elevation
+ * bracket apply_hrtf.py:199-215, :261-266) is host logic; this entry point does
+ * all table arithmetic (:219-279).
+ *   idx [n][4] int32 = (top_before, top_after, bot_before, bot_after)
+ *   w   [n][3] f64   = (top_alpha, bot_alpha, a)
+ *   H   [n][2 ears][L] f32                                        */
+int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *idx,
+                     const double *w, int n, int ndir, int L, int U, float *H,
+                     bas_stream_t stream);
+
+/* ---- a7/a8: make_signal_move_2d inner loops (apply_hrtf.py:431-453) ---------
+ * For every source s, input sample m and tap k:
+ *   y[e][m+k] += x[s][m] * ((1-al) H[s][c][e][k] + al H[s][c+1][e][k]),
+ *   c = m / K,  al = ((m % K) / S) * S / K            (:442-443, :445-446, :450-453)
+ * i.e. per-subchunk crossfaded IR, direct-form FIR (what scipy.signal.convolve
+ * resolves to at these sizes), overlap-add, summed over sources.
+ *   x  [n_src] rows of T_in floats, row stride x_stride floats; T_in % K == 0
+ *      (the caller zero-pads as apply_hrtf.py:405-406 does)
+ *   H  [n_src][T_in/K + 1][2][L] f32 (bas_interp2d_f32 output, chunk IRs at
+ *      t = 0, K, .., T_in; :429, :435)
+ *   y  [2][T_in + L - 1] f32; overwritten, or added to when accumulate != 0
+ *   peak (may be NULL): device float receiving max|y| of the result (:462),
+ *      fused into the final pass
+ *   ws / ws_bytes: scratch of at least bas_render_workspace_bytes(...) bytes. */
+size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S, int L);
+
+int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,
+                       int K, int S, int L, float *y, int accumulate, float *peak,
+                       void *ws, size_t ws_bytes, bas_stream_t stream);
+
+/* ---- a7 (vii): peak normalisation (apply_hrtf.py:462-464) -------------------
+ * m = max|y| over n floats; *peak = m (device float, may be NULL when apply);
+ * if apply and m > 1: y /= m. */
+int bas_peak_normalize_f32(float *y, long n, float *peak, int apply, bas_stream_t stream);
+
+/* y /= *peak if *peak > 1 (second half of the rule, for a peak already known,
+ * e.g. reduced across GPUs). */
+int bas_scale_by_peak_f32(float *y, long n, const float *peak, bas_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BAS_H */

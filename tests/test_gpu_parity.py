@@ -1,0 +1,202 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the reference-generated
+golden vectors and against the CPU oracle on seeded inputs.
+
+Tolerance: 1e-5 norm-relative in float32 (BASELINE.json north_star), i.e.
+max|got - want| / max|want| <= 1e-5, written REL below.
+"""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+from oracle import bas_oracle as orc
+import binaural_audio_synthesis_amd as bas
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev_tables(tables):
+    out = {}
+    for name, t in tables.items():
+        for l in (128, 100):
+            h = t.truncated(l)
+            out[(name, l)] = (h, bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right,
+                                                        h.irs_left, h.irs_right))
+    return out
+
+
+def test_library_is_the_hip_one():
+    import torch
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    assert bas._hip.lib().bas_version() == 1
+
+
+def test_table_pack_layout(dev_tables):
+    h, d = dev_tables[("consistent", 128)]
+    packed = d.packed.cpu().numpy()                     # [2][187][8][128]
+    want = np.stack([h.irs_left, h.irs_right]).astype(np.float32).reshape(2, 187, 128, 8).transpose(0, 1, 3, 2)
+    assert np.array_equal(packed.reshape(2, 187, 8, 128), want)
+
+
+def test_delay_signal_float_golden():
+    g = golden("delay_signal.npz")
+    for i, s in enumerate(g["shifts"]):
+        for down in (1, 8):
+            got = bas.delay_signal_float(g["x"], float(s), down)
+            want = g[f"y{i}_d{down}"]
+            assert got.shape == want.shape
+            assert rel_err(got, want) <= REL, (i, s, down)
+
+
+def test_ring_interp_golden(dev_tables):
+    g = golden("ring_interp.npz")
+    names = {0: "consistent", 1: "adversarial"}
+    for k in range(int(g["n"])):
+        kind, p, q, alpha, up = g[f"c{k}_meta"]
+        dl, dr, irs = bas.delay_compensated_interpolation_with_delaydiff(
+            dev_tables[(names[int(kind)], 128)][1], int(p), int(q), alpha, bool(up))
+        assert irs.shape == g[f"c{k}_irs"].shape
+        assert rel_err(irs, g[f"c{k}_irs"]) <= REL, k
+        assert np.allclose([dl, dr], g[f"c{k}_delays"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("tname", ["consistent", "adversarial"])
+@pytest.mark.parametrize("l", [128, 100])
+def test_interpolate_2d_golden(dev_tables, tname, l):
+    g = golden("interp2d.npz")
+    _, d = dev_tables[(tname, l)]
+    want = g[f"{tname}_{l}"]
+    pts = g["points"]
+    got = bas.interpolate_2d_batch(d, pts[:, 0], pts[:, 1]).cpu().numpy()
+    assert got.shape == want.shape
+    peak = np.abs(want).max()
+    worst = np.abs(got - want).max(axis=(1, 2)) / peak
+    assert worst.max() <= REL, (int(worst.argmax()), float(worst.max()))
+    # scalar drop-in form, a few points incl. clamp / pole
+    for i in (0, 5, len(pts) - 1, len(pts) - 2, len(pts) - 7):
+        one = bas.interpolate_2d(d, np.float64(pts[i, 0]), np.float64(pts[i, 1]))
+        assert one.shape == (2, l) and rel_err(one, want[i]) <= REL
+
+
+RENDER_CASES = ["circle_512_32_128", "sweep_512_32_128", "spiral_512_32_128", "spiral_512_512_128",
+                "askew_128_16_100", "spiral_512_32_100", "loud_512_32_128", "silent_512_32_128",
+                "exact_multiple_256_8_128", "short_512_32_128"]
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_make_signal_move_2d_golden(dev_tables, name):
+    g = golden(f"render_{name}.npz")
+    meta = json.loads(str(g["meta"]))
+    _, d = dev_tables[(meta["table"], meta["L"])]
+    traj = bas.synth.trajectory(meta["traj"], fs=meta["fs"], **meta["traj_kw"])
+    got = bas.make_signal_move_2d(g["x"], meta["K"], meta["S"], traj, d)
+    want = g["y"]
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32 and got.shape == want.shape
+    assert rel_err(got, want) <= REL, rel_err(got, want)
+    if name.startswith("loud"):
+        assert abs(np.abs(got).max() - 1.0) < 1e-6
+
+
+def test_make_signal_move_2d_pyfloat_trajectory(dev_tables):
+    g = golden("render_pyfloat_circle.npz")
+    meta = json.loads(str(g["meta"]))
+    k = 2 * np.pi / (meta["period_s"] * meta["fs"])
+    traj = lambda t: (0, (k * t) % (2 * np.pi))         # noqa: E731  the CLI's lambda form
+    got = bas.make_signal_move_2d(g["x"], meta["K"], meta["S"], traj, dev_tables[("consistent", 128)][1])
+    assert rel_err(got, g["y"]) <= REL
+
+
+def test_reference_error_behaviour(dev_tables):
+    _, d = dev_tables[("consistent", 128)]
+    traj = bas.synth.trajectory("circle_horizontal")
+    with pytest.raises(AssertionError):
+        bas.make_signal_move_2d(np.zeros((10, 2), dtype=np.float32), 512, 32, traj, d)    # apply_hrtf.py:398
+    with pytest.raises(AssertionError):
+        bas.make_signal_move_2d(np.zeros(100, dtype=np.float32), 512, 48, traj, d)        # :402
+    empty = bas.make_signal_move_2d(np.zeros(0, dtype=np.float32), 512, 32, traj, d)
+    assert empty.shape == (127, 2) and not empty.any()
+
+
+def test_device_tensor_in_device_tensor_out(dev_tables):
+    import torch
+    g = golden("render_spiral_512_32_128.npz")
+    meta = json.loads(str(g["meta"]))
+    _, d = dev_tables[("consistent", 128)]
+    traj = bas.synth.trajectory(meta["traj"], fs=meta["fs"], **meta["traj_kw"])
+    x = torch.from_numpy(g["x"]).cuda()
+    got = bas.make_signal_move_2d(x, 512, 32, traj, d)
+    assert isinstance(got, torch.Tensor) and got.is_cuda and got.shape == g["y"].shape
+    assert got.stride() == (1, got.shape[0])            # same F-order as the reference's .T view
+    assert rel_err(got.cpu().numpy(), g["y"]) <= REL
+
+
+def _mix_case(h, n_src, n, k, s, seed):
+    sigs = np.stack([bas.synth.integer_noise(seed + i, n, 0.5 / n_src) for i in range(n_src)])
+    in_length, _ = orc.render_lengths(n, k, orc.ir_length(h))
+    t = np.arange(0, in_length + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        name = ("spiral", "circle_askew", "circle_horizontal", "passing")[i % 4]
+        tr = bas.synth.trajectory(name, period_s=0.05 + 0.01 * i, length_s=n / 44100, turns=2.0 + i,
+                                  phase=2 * np.pi * i / n_src)
+        elev[i], azim[i] = tr(t)
+    irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(t.size)]) for i in range(n_src)]
+    return sigs, elev, azim, irs
+
+
+@pytest.mark.parametrize("n_src,n,k,s,l", [(5, 9000, 512, 32, 128), (3, 5000, 512, 64, 100),
+                                           (7, 20000, 256, 32, 128), (2, 3000, 128, 16, 128),
+                                           (33, 2500, 512, 32, 128)])
+def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
+    """Multi-source mix (fast kernel for S % 32 == 0, generic kernel otherwise)."""
+    h, d = dev_tables[("consistent", l)]
+    sigs, elev, azim, irs = _mix_case(h, n_src, n, k, s, seed=100)
+    want = orc.render_mix(sigs, k, s, irs)
+    got = bas.render_sources(sigs, k, s, elev, azim, d).cpu().numpy()
+    assert got.shape == want.shape and np.abs(want).max() < 1.0
+    assert rel_err(got, want) <= REL, rel_err(got, want)
+
+
+def test_long_ir_segments(tables):
+    """L = 300 > 128 exercises the 128-tap segment loop of the fast kernel."""
+    h = tables["consistent"].truncated(300)
+    d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    sigs, elev, azim, irs = _mix_case(h, 2, 7000, 512, 32, seed=300)
+    want = orc.render_mix(sigs, 512, 32, irs)
+    got = bas.render_sources(sigs, 512, 32, elev, azim, d).cpu().numpy()
+    assert rel_err(got, want) <= REL, rel_err(got, want)
+
+
+def test_linearity_and_determinism_at_full_size(dev_tables):
+    """BASELINE-size properties (oracle too slow here): render(a+b) = render(a)+render(b) with
+    normalisation off, bitwise run-to-run determinism, and chunk-aligned time invariance."""
+    import torch
+    h, d = dev_tables[("consistent", 128)]
+    n_src, n, k, s = 16, 441000, 512, 32
+    in_length = -(-n // k) * k
+    t = np.arange(0, in_length + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        tr = bas.synth.trajectory("spiral", length_s=10.0, turns=5.0, phase=2 * np.pi * i / n_src)
+        elev[i], azim[i] = tr(t)
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    a = (torch.rand((n_src, n), generator=gen, device="cuda") - 0.5) * (0.5 / n_src)
+    b = (torch.rand((n_src, n), generator=gen, device="cuda") - 0.5) * (0.5 / n_src)
+    ya = bas.render_sources(a, k, s, elev, azim, d, normalize="none")
+    yb = bas.render_sources(b, k, s, elev, azim, d, normalize="none")
+    yab = bas.render_sources(a + b, k, s, elev, azim, d, normalize="none")
+    ya2 = bas.render_sources(a, k, s, elev, azim, d, normalize="none")
+    assert torch.equal(ya, ya2)                                          # deterministic reduction order
+    scale = float(yab.abs().max())
+    assert float((yab - (ya + yb)).abs().max()) / scale <= 2e-6
+    # mix of all sources == sum of single-source renders
+    singles = sum(bas.render_sources(a[i:i + 1], k, s, elev[i:i + 1], azim[i:i + 1], d, normalize="none")
+                  for i in range(n_src))
+    assert float((ya - singles).abs().max()) / float(ya.abs().max()) <= 2e-6
+    assert ya.shape == (in_length + 127, 2)
