@@ -135,7 +135,7 @@ def test_device_tensor_in_device_tensor_out(dev_tables):
 
 
 def _mix_case(h, n_src, n, k, s, seed):
-    sigs = np.stack([bas.synth.integer_noise(seed + i, n, 0.5 / n_src) for i in range(n_src)])
+    sigs = np.stack([bas.synth.integer_noise(seed + i, n, 0.1 / n_src) for i in range(n_src)])
     in_length, _ = orc.render_lengths(n, k, orc.ir_length(h))
     t = np.arange(0, in_length + 1, k, dtype=np.float64)
     elev = np.empty((n_src, t.size))
