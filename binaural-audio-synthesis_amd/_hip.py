@@ -25,8 +25,12 @@ SIGNATURES = {
     "bas_render_workspace_bytes": (_c_size_t, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_mix_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_int,
                                     _c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
+    "bas_render_mix_profiled_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_long, _c_int, _c_int,
+                                             _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t,
+                                             _c_void_p, _c_void_p, _c_void_p]),
     "bas_peak_normalize_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_void_p]),
     "bas_scale_by_peak_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
+    "bas_mix_partials_f32": (_c_int, [_c_void_p, _c_int, _c_long, _c_long, _c_void_p, _c_void_p, _c_void_p]),
 }
 
 _lib = None

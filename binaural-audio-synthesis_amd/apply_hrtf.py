@@ -123,10 +123,11 @@ def delay_compensated_interpolation_with_delaydiff(irs_and_delaydiffs, before: i
 # --------------------------------------------------------------------------
 # a6
 # --------------------------------------------------------------------------
-def interpolate_2d_params(tbl, idx, w):
+def interpolate_2d_params(tbl, idx, w, out=None, validate=True):
     """Batched table arithmetic of interpolate_2d (apply_hrtf.py:219-279) for
     precomputed parameters: idx int32 [n,4], w float64 [n,3] (numpy or device
-    tensors).  Returns a device tensor [n, 2, L] float32."""
+    tensors).  Returns a device tensor [n, 2, L] float32 (`out` if given).
+    validate=False skips the index range check (a host<->device sync)."""
     import torch
     tbl = as_device_table(tbl)
     dev = tbl.device
@@ -135,9 +136,9 @@ def interpolate_2d_params(tbl, idx, w):
     n = idx_t.shape[0]
     if w_t.shape[0] != n:
         raise ValueError("idx and w disagree on the number of queries")
-    if n and (int(idx_t.min()) < 0 or int(idx_t.max()) >= tbl.ndir):
+    if validate and n and (int(idx_t.min()) < 0 or int(idx_t.max()) >= tbl.ndir):
         raise IndexError("HRTF database index out of range")
-    H = torch.empty((n, 2, tbl.L), dtype=torch.float32, device=dev)
+    H = out if out is not None else torch.empty((n, 2, tbl.L), dtype=torch.float32, device=dev)
     _hip.call("bas_interp2d_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(idx_t), _hip.ptr(w_t), n,
               tbl.ndir, tbl.L, tbl.upsampling, _hip.ptr(H), _hip.current_stream(dev))
     return H
@@ -172,9 +173,11 @@ def render_lengths(n, chunksize, ir_length):
     return in_length, in_length + ir_length - 1                             # :410
 
 
-def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=None, accumulate=False):
+def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=None, accumulate=False,
+                  events=None, ws=None):
     """Core launch: x [n_src, T_in] device float32 (T_in % K == 0), H [n_src, n_chunks+1, 2, L].
-    Returns (y [2, T_out] device float32, peak device scalar)."""
+    Returns (y [2, T_out] device float32, peak device scalar).  `events` = (begin, end) raw
+    hipEvent_t handles recorded around the FIR kernel (bench.py); `ws` = reusable workspace."""
     import torch
     dev = x.device
     n_src, t_in = x.shape
@@ -182,11 +185,15 @@ def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=Non
     y = out if out is not None else torch.empty((2, t_out), dtype=torch.float32, device=dev)
     peak = torch.empty((1,), dtype=torch.float32, device=dev)
     ws_bytes = _hip.lib().bas_render_workspace_bytes(n_src, t_in, chunksize, subchunksize, tbl_L)
-    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    if ws is None or ws.numel() < ws_bytes:
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     stream = _hip.current_stream(dev)
-    _hip.call("bas_render_mix_f32", _hip.ptr(x), x.stride(0) if n_src else t_in, _hip.ptr(H), n_src, t_in,
-              chunksize, subchunksize, tbl_L, _hip.ptr(y), int(bool(accumulate)), _hip.ptr(peak), _hip.ptr(ws),
-              ws_bytes, stream)
+    args = (_hip.ptr(x), x.stride(0) if n_src else t_in, _hip.ptr(H), n_src, t_in, chunksize, subchunksize, tbl_L,
+            _hip.ptr(y), int(bool(accumulate)), _hip.ptr(peak), _hip.ptr(ws), ws.numel(), stream)
+    if events is None:
+        _hip.call("bas_render_mix_f32", *args)
+    else:
+        _hip.call("bas_render_mix_profiled_f32", *args, events[0], events[1])
     if normalize == "mix":
         _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(peak), stream)   # :462-464
     elif normalize != "none":

@@ -350,6 +350,24 @@ __global__ __launch_bounds__(256) void bas_scale_kernel(float *__restrict__ y, l
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) y[i] = y[i] / m;
 }
 
+// fixed-order sum of partial mixes (one per GPU) + fused max|y|
+__global__ __launch_bounds__(256) void bas_mix_partials_kernel(const float *__restrict__ parts, int n_parts,
+                                                                 long part_stride, long n,
+                                                                 float *__restrict__ y,
+                                                                 unsigned int *peak_bits) {
+    float lmax = 0.f;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        float v = 0.f;
+        for (int p = 0; p < n_parts; ++p) v += parts[p * part_stride + i];
+        y[i] = v;
+        lmax = fmaxf(lmax, fabsf(v));
+    }
+    if (peak_bits) {
+        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+        if ((threadIdx.x & 63) == 0) atomicMax(peak_bits, __float_as_uint(lmax));
+    }
+}
+
 static int grid_for(long items, int cap) {
     long g = (items + 255) / 256;
     if (g < 1) g = 1;
@@ -395,9 +413,9 @@ extern "C" size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S,
     return (p.fast ? p.slab_bytes : 0) + 16;
 }
 
-extern "C" int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,
-                                  int K, int S, int L, float *y, int accumulate, float *peak, void *ws,
-                                  size_t ws_bytes, bas_stream_t stream) {
+static int render_mix_impl(const float *x, long x_stride, const float *H, int n_src, long T_in, int K, int S,
+                           int L, float *y, int accumulate, float *peak, void *ws, size_t ws_bytes,
+                           bas_stream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
     BAS_REQUIRE(y, BAS_E_NULL, "bas_render_mix_f32: y is null");
     BAS_REQUIRE(n_src >= 0 && T_in >= 0 && K > 0 && S > 0 && L > 0, BAS_E_SHAPE,
                 "bas_render_mix_f32: need n_src>=0, T_in>=0, K,S,L>0 (n_src=%d T_in=%ld K=%d S=%d L=%d)",
@@ -422,8 +440,10 @@ extern "C" int bas_render_mix_f32(const float *x, long x_stride, const float *H,
     const int live_src = T_in == 0 ? 0 : n_src;
     RenderPlan p = plan_render(live_src, T_in, K, S, L, aligned);
     if (!p.fast) {
+        if (ev_begin) (void)hipEventRecord(ev_begin, st);
         hipLaunchKernelGGL(bas_render_generic_kernel, dim3(grid_for(T_out, 8192)), dim3(256), 0, st, x, x_stride,
                            H, live_src, T_in, K, S, L, n_chunks, T_out, y, accumulate, peak_bits);
+        if (ev_end) (void)hipEventRecord(ev_end, st);
         return bas_check_launch("bas_render_mix_f32(generic)");
     }
     BAS_REQUIRE(ws && ws_bytes >= p.slab_bytes, BAS_E_WORKSPACE,
@@ -436,13 +456,30 @@ extern "C" int bas_render_mix_f32(const float *x, long x_stride, const float *H,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bas_render_rows32_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES);
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    if (ev_begin) (void)hipEventRecord(ev_begin, st);
     hipLaunchKernelGGL(bas_render_rows32_kernel, dim3(p.n_wg), dim3(RT_THREADS), RT_LDS_BYTES, st, A);
+    if (ev_end) (void)hipEventRecord(ev_end, st);
     int rc = bas_check_launch("bas_render_mix_f32(rows32)");
     if (rc) return rc;
     hipLaunchKernelGGL(bas_slab_reduce_kernel, dim3(grid_for((T_out + 3) / 4, 2048)), dim3(256), 0, st,
                        A.slab, live_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
                        peak_bits);
     return bas_check_launch("bas_render_mix_f32(reduce)");
+}
+
+extern "C" int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,
+                                  int K, int S, int L, float *y, int accumulate, float *peak, void *ws,
+                                  size_t ws_bytes, bas_stream_t stream) {
+    return render_mix_impl(x, x_stride, H, n_src, T_in, K, S, L, y, accumulate, peak, ws, ws_bytes, stream,
+                           nullptr, nullptr);
+}
+
+extern "C" int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,
+                                           int K, int S, int L, float *y, int accumulate, float *peak,
+                                           void *ws, size_t ws_bytes, bas_stream_t stream, void *ev_begin,
+                                           void *ev_end) {
+    return render_mix_impl(x, x_stride, H, n_src, T_in, K, S, L, y, accumulate, peak, ws, ws_bytes, stream,
+                           reinterpret_cast<hipEvent_t>(ev_begin), reinterpret_cast<hipEvent_t>(ev_end));
 }
 
 extern "C" int bas_peak_normalize_f32(float *y, long n, float *peak, int apply, bas_stream_t stream) {
@@ -466,4 +503,21 @@ extern "C" int bas_scale_by_peak_f32(float *y, long n, const float *peak, bas_st
     if (n == 0) return 0;
     hipLaunchKernelGGL(bas_scale_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, bas_stream(stream), y, n, peak);
     return bas_check_launch("bas_scale_by_peak_f32");
+}
+
+extern "C" int bas_mix_partials_f32(const float *parts, int n_parts, long part_stride, long n, float *y,
+                                    float *peak, bas_stream_t stream) {
+    BAS_REQUIRE(y || n == 0, BAS_E_NULL, "bas_mix_partials_f32: y is null");
+    BAS_REQUIRE(parts || n_parts == 0 || n == 0, BAS_E_NULL, "bas_mix_partials_f32: parts is null");
+    BAS_REQUIRE(n >= 0 && n_parts >= 0 && part_stride >= n, BAS_E_SHAPE,
+                "bas_mix_partials_f32: need n>=0, n_parts>=0, part_stride>=n");
+    hipStream_t st = bas_stream(stream);
+    if (peak) {
+        hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);
+        if (e != hipSuccess) return bas_fail((int)e, "bas_mix_partials_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(bas_mix_partials_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, parts, n_parts,
+                       part_stride, n, y, reinterpret_cast<unsigned int *>(peak));
+    return bas_check_launch("bas_mix_partials_f32");
 }

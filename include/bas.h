@@ -108,6 +108,14 @@ int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src,
                        int K, int S, int L, float *y, int accumulate, float *peak,
                        void *ws, size_t ws_bytes, bas_stream_t stream);
 
+/* Same call; additionally records the caller's hipEvent_t pair (passed as void*, either
+ * may be NULL) on `stream` immediately before and after the FIR kernel, so a
+ * benchmark can time the dominant kernel live with HIP events. */
+int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, int n_src,
+                                long T_in, int K, int S, int L, float *y, int accumulate,
+                                float *peak, void *ws, size_t ws_bytes, bas_stream_t stream,
+                                void *ev_begin, void *ev_end);
+
 /* ---- a7 (vii): peak normalisation (apply_hrtf.py:462-464) -------------------
  * m = max|y| over n floats; *peak = m (device float, may be NULL when apply);
  * if apply and m > 1: y /= m. */
@@ -116,6 +124,13 @@ int bas_peak_normalize_f32(float *y, long n, float *peak, int apply, bas_stream_
 /* y /= *peak if *peak > 1 (second half of the rule, for a peak already known,
  * e.g. reduced across GPUs). */
 int bas_scale_by_peak_f32(float *y, long n, const float *peak, bas_stream_t stream);
+
+/* ---- multi-GPU combine (no reference counterpart; DESIGN.md "Multi-GPU") ------
+ * y[i] = parts[0][i] + parts[1][i] + ... in that fixed order (deterministic),
+ * parts[p] at parts + p*part_stride, n floats each; *peak = max|y| (may be NULL).
+ * Used on the root rank after the RCCL gather of the per-GPU partial mixes. */
+int bas_mix_partials_f32(const float *parts, int n_parts, long part_stride, long n, float *y,
+                         float *peak, bas_stream_t stream);
 
 #ifdef __cplusplus
 }
