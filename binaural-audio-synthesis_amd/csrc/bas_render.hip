@@ -24,6 +24,8 @@
 // footprint (68 IR rows + x window = 79.4 KB) is independent of L and two
 // workgroups share a CU.  No MFMA: this is a 1-D FIR (BASELINE.json north_star).
 #include "bas_internal.h"
+#include <stdlib.h>
+#include <string.h>
 
 #define RT_THREADS 256
 #define RT_TILE 2048            // outputs per tile: 64 lanes x 32
@@ -45,7 +47,18 @@ struct RenderArgs {
     int units_per_wg;
     int parts_per_wg;
     float *slab;           // [n_wg][parts_per_wg][2][RT_TILE]
+    int dbg;               // ablation flags (BAS_DEBUG_FLAGS, diagnostics only)
 };
+
+#ifdef BAS_STAMPS
+// Diagnostic build only (make stamps): per-wave cycle totals of the pass loop phases.
+__device__ unsigned long long bas_dbg_stamps[1024 * 4 * 8];
+#define STAMP(var) unsigned long long var = __builtin_readcyclecounter()
+#define STAMP_ADD(slot, t0, t1) st_acc[slot] += (t1) - (t0)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, t0, t1)
+#endif
 
 struct Win {
     f32x2 t[8];            // 8 taps x (left,right)
@@ -100,6 +113,77 @@ __device__ __forceinline__ void load_x8(float (&x)[8], const f32x4 *__restrict__
     x[4] = hi.x; x[5] = hi.y; x[6] = hi.z; x[7] = hi.w;
 }
 
+#define RT_NH 8                 // chunk IRs a thread keeps in registers per pass
+#define RT_NX 3                 // float4 of x per thread per pass: ceil(68*8 / 256)
+
+// One LDS pass = one (tile, source) work unit x one 128-tap segment.
+struct Pass {
+    long tile;
+    int s, seg0, Lseg;
+    long top;          // n0 - seg0: output-aligned origin of the input window (multiple of 32)
+    long xbase;        // first input sample held in LDS (multiple of 32, may be negative)
+    int nrows;         // rows of 32 inputs staged
+    int c0;            // floor(xbase / K): chunk of the first row (negative before the signal)
+    int mo0;           // offset of the first row inside its chunk (multiple of 32)
+};
+
+__device__ __forceinline__ Pass make_pass(const RenderArgs &A, long unit0, int nseg, long pid) {
+    Pass P;
+    const long unit = unit0 + pid / nseg;
+    const int sg = (int)(pid % nseg);
+    P.tile = unit / A.n_src;
+    P.s = (int)(unit - P.tile * A.n_src);
+    P.seg0 = sg * RT_SEG;
+    P.Lseg = A.Lp - P.seg0 < RT_SEG ? A.Lp - P.seg0 : RT_SEG;              // multiple of 8
+    P.top = P.tile * RT_TILE - P.seg0;
+    const long rho0 = (P.top - P.Lseg) >> 5;                               // floor
+    P.xbase = rho0 << 5;
+    P.nrows = (int)((P.top >> 5) + RT_TILE / 32 - rho0);                   // <= RT_ROWS
+    // floor division that stays consistent across 0 (rows before the signal only meet x = 0,
+    // they just need finite IR values)
+    long cf = P.xbase / A.K;
+    if (cf * A.K > P.xbase) --cf;
+    P.c0 = (int)cf;
+    P.mo0 = (int)(P.xbase - cf * A.K);
+    return P;
+}
+
+// Register image of one pass's global loads: every thread holds its share of the x window and,
+// as lane l of its wave, the chunk IRs H[c0 .. c0+RT_NH-1][both ears][taps 2l, 2l+1] (L is even on
+// this path).  Every load is unconditional with a clamped address (no branches); values that must
+// read as zero are masked when they are consumed.  The loads are issued at the top of a loop
+// iteration and consumed at its end, never carried across the back edge: loop-carried load results
+// made hipcc copy them behind an early s_waitcnt vmcnt(0), serialising load latency and FIR.
+struct Prefetch {
+    f32x4 xv[RT_NX];
+    f32x2 hl[RT_NH], hr[RT_NH];    // left / right ear, taps (2l, 2l+1)
+};
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+__device__ __forceinline__ void prefetch_h(Prefetch &F, const RenderArgs &A, const Pass &P, int c_first,
+                                            int lane) {
+    int k = P.seg0 + 2 * lane;
+    if (k > A.L - 2) k = A.L - 2;                            // L even: stays 8-byte aligned
+    const float *Hk = A.H + ((long)P.s * (A.n_chunks + 1)) * 2 * A.L + k;
+#pragma unroll
+    for (int j = 0; j < RT_NH; ++j) {
+        const float *p = Hk + (long)clampi(c_first + j, 0, A.n_chunks) * 2 * A.L;
+        F.hl[j] = *reinterpret_cast<const f32x2 *>(p);
+        F.hr[j] = *reinterpret_cast<const f32x2 *>(p + A.L);
+    }
+}
+
+__device__ __forceinline__ void prefetch_x(Prefetch &F, const RenderArgs &A, const Pass &P, int tid) {
+    const float *xsrc = A.x + (long)P.s * A.x_stride;
+#pragma unroll
+    for (int j = 0; j < RT_NX; ++j) {
+        long m = P.xbase + 4L * (tid + j * RT_THREADS);
+        m = m < 0 ? 0 : (m > A.T_in - 4 ? A.T_in - 4 : m);
+        F.xv[j] = *reinterpret_cast<const f32x4 *>(xsrc + m);
+    }
+}
+
 __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(RenderArgs A) {
     extern __shared__ f32x4 lds4[];
     float *gs = reinterpret_cast<float *>(lds4);             // [RT_ROWS][RT_RS]
@@ -112,6 +196,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
     const long unit0 = (long)blockIdx.x * A.units_per_wg;
     long unit1 = unit0 + A.units_per_wg;
     if (unit1 > A.units_total) unit1 = A.units_total;
+    const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
+    const long n_pass = (unit1 - unit0) * nseg;
 
     f32x2 acc[8];
 #pragma unroll
@@ -133,112 +219,405 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
         for (int r = 0; r < 8; ++r) acc[r] = f32x2{0.f, 0.f};
     };
 
-    for (long unit = unit0; unit < unit1; ++unit) {
+    if (n_pass <= 0) return;
+    const float invK = 1.0f / (float)A.K;
+    const bool s_pow2 = (A.S & (A.S - 1)) == 0;
+
+    auto load_pass = [&](Prefetch &F, const Pass &P) {
+        prefetch_x(F, A, P, tid);
+        prefetch_h(F, A, P, P.c0, lane);
+    };
+
+    // ---- registers of pass P -> LDS: the x window (all threads) and the crossfaded IR of every row.
+    // Wave w writes rows w, w+4, ..; lane l of it the taps 2l, 2l+1 of both ears (one ds_write_b128):
+    //   G_row = H_c + al (H_{c+1} - H_c),  al = subchunk offset / K            (apply_hrtf.py:442-443)
+    auto stage_pass = [&](Prefetch &F, const Pass &P) {
+        const int nrows = P.nrows;
+        // column-major image, xs4[c][r] = x[xbase + 32 r + 4 c .. +3]
+#pragma unroll
+        for (int j = 0; j < RT_NX; ++j) {
+            const int i4 = tid + j * RT_THREADS;
+            const long m = P.xbase + 4L * i4;
+            const bool inside = m >= 0 && m < A.T_in;
+            f32x4 v = F.xv[j];
+            v = inside ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i4 < nrows * 8) xs4[(i4 & 7) * RT_XR + (i4 >> 3)] = v;
+        }
+        if (2 * lane < P.Lseg && !(A.dbg & 1)) {
+            const int k0 = P.seg0 + 2 * lane;
+            const f32x2 live = f32x2{k0 < A.L ? 1.0f : 0.0f, k0 + 1 < A.L ? 1.0f : 0.0f};   // taps >= L are zero
+            f32x4 *gdst = reinterpret_cast<f32x4 *>(gs) + lane;
+            int c = P.c0, mo = P.mo0;
+            int r = 0;                                       // first row of the current chunk slot
+            while (r < nrows) {
+#pragma unroll
+                for (int j = 0; j < RT_NH - 1; ++j) {
+                    int r_end = r + ((A.K - mo) >> 5);       // rows left in this chunk
+                    if (r_end > nrows) r_end = nrows;
+                    const f32x2 h0l = F.hl[j] * live, h0r = F.hr[j] * live;
+                    const f32x2 dl = (F.hl[j + 1] - F.hl[j]) * live, dr = (F.hr[j + 1] - F.hr[j]) * live;
+                    // this wave's rows inside [r, r_end): r + ((u - r) mod 4), step 4
+                    for (int rr = r + ((u - r) & 3); rr < r_end; rr += 4) {
+                        const int m_in = mo + ((rr - r) << 5);                   // offset inside the chunk
+                        const float al = (float)(m_in - (s_pow2 ? (m_in & (A.S - 1)) : m_in % A.S)) * invK;
+                        const f32x2 gl = __builtin_elementwise_fma(dl, f32x2{al, al}, h0l);
+                        const f32x2 gr = __builtin_elementwise_fma(dr, f32x2{al, al}, h0r);
+                        gdst[rr * (RT_RS / 4)] = f32x4{gl.x, gr.x, gl.y, gr.y};  // [tap][ear]
+                    }
+                    mo += (r_end - r) << 5;
+                    r = r_end;
+                    if (mo >= A.K) {
+                        mo = 0;
+                        ++c;
+                    }
+                }
+                if (r < nrows) prefetch_h(F, A, P, c, lane);  // small K: next batch of chunk IRs on demand
+            }
+        }
+    };
+
+    // ---- FIR of the pass staged in LDS: blocks q = 0..Q; block q = inputs [n_t - seg0 - 8q, +8) x taps
+    // seg0 + 8q-7 .. 8q+7.  Block q of wave u sits at 8-block cp = (u - q) mod 4 of its row, so a wave
+    // enters a new (previous) row at q = u+1, u+5, ...  Blocks 0..u (top row) and the tail are handled
+    // one by one; in between, groups of four blocks [enter row, slide, slide, slide] run with fixed
+    // register roles and immediate LDS offsets (no copies, no address arithmetic).
+    auto fir_pass = [&](const Pass &P) {
+        const int Q = P.Lseg >> 3;                           // 8-tap groups in this segment
+        Win wx, wy;
+        float x8[8];
+        const int rsh = (int)((P.top - P.xbase) >> 5);       // rows above the tile's first input row
+        const int off_top = 32 * rsh + 8 * u;
+        auto generic_mid = [&](int q) {                      // any middle block, both halves loaded
+            const int off = off_top - 8 * q;
+            const int r = lane + (off >> 5), cp = (off & 31) >> 3;
+            const float *grow = gs + r * RT_RS + 16 * q;
+            load_x8(x8, xs4, cp, r);
+            win_load(wx, grow - 16);
+            win_load(wy, grow);
+            fir_mid(acc, x8, wx, wy);
+        };
+        {                                                    // q = 0: taps 0..7 only
+            const int r = lane + rsh;
+            load_x8(x8, xs4, u, r);
+            win_load(wy, gs + r * RT_RS);
+            fir_first(acc, x8, wy);
+        }
+        int q = 1;
+        for (; q <= u && q < Q; ++q) generic_mid(q);         // rest of the top row
+        if (q == u + 1) {
+            const float *gp = gs + (lane + rsh - 1) * RT_RS + 16 * q;
+            const f32x4 *xp = xs4 + (lane + rsh - 1);
+            for (; q + 3 < Q; q += 4) {
+                auto xld = [&](int cp) {
+                    f32x4 lo = xp[(2 * cp) * RT_XR], hi = xp[(2 * cp + 1) * RT_XR];
+                    x8[0] = lo.x; x8[1] = lo.y; x8[2] = lo.z; x8[3] = lo.w;
+                    x8[4] = hi.x; x8[5] = hi.y; x8[6] = hi.z; x8[7] = hi.w;
+                };
+                xld(3);                                      // enter the row: both halves
+                win_load(wx, gp - 16);
+                win_load(wy, gp);
+                fir_mid(acc, x8, wx, wy);
+                xld(2);
+                win_load(wx, gp + 16);
+                fir_mid(acc, x8, wy, wx);
+                xld(1);
+                win_load(wy, gp + 32);
+                fir_mid(acc, x8, wx, wy);
+                xld(0);
+                win_load(wx, gp + 48);
+                fir_mid(acc, x8, wy, wx);
+                gp += 64 - RT_RS;
+                xp -= 1;
+            }
+        }
+        for (; q < Q; ++q) generic_mid(q);                   // tail middles
+        {                                                    // q = Q: the last 8 taps only
+            const int off = off_top - 8 * Q;
+            const int r = lane + (off >> 5), cp = (off & 31) >> 3;
+            load_x8(x8, xs4, cp, r);
+            win_load(wx, gs + r * RT_RS + 16 * Q - 16);
+            fir_last(acc, x8, wx);
+        }
+    };
+
+#ifdef BAS_STAMPS
+    unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = __builtin_readcyclecounter();
+#endif
+    Pass P = make_pass(A, unit0, nseg, 0);
+    {
+        Prefetch F0;
+        load_pass(F0, P);
+        stage_pass(F0, P);
+    }
+    __syncthreads();
+    for (long pid = 0; pid < n_pass; ++pid) {
+        // loads of the NEXT pass are issued here and consumed after this pass's FIR, inside the same
+        // iteration (the last iteration re-loads its own pass: harmless, keeps the loads unconditional)
+        const bool has_next = pid + 1 < n_pass;
+        const Pass N = make_pass(A, unit0, nseg, has_next ? pid + 1 : pid);
+        Prefetch F;
+        STAMP(t0);
+        load_pass(F, N);
+        if (P.tile != cur_tile) {
+            flush(cur_tile);
+            cur_tile = P.tile;
+        }
+        STAMP(t1);
+        if (!(A.dbg & 2)) fir_pass(P);
+        STAMP(t2);
+        __syncthreads();                                     // every wave has finished reading LDS
+        STAMP(t3);
+#ifdef BAS_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(t3b);
+        STAMP_ADD(5, t3, t3b);
+#endif
+        if (has_next) stage_pass(F, N);
+        STAMP(t4);
+        __syncthreads();
+        STAMP(t5);
+        STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t2); STAMP_ADD(2, t2, t3); STAMP_ADD(3, t3, t4); STAMP_ADD(4, t4, t5);
+        P = N;
+    }
+#ifdef BAS_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        for (int i = 0; i < 6; ++i) bas_dbg_stamps[(blockIdx.x * 4 + u) * 8 + (i < 5 ? i : 6)] = st_acc[i];
+        bas_dbg_stamps[(blockIdx.x * 4 + u) * 8 + 5] = __builtin_readcyclecounter() - st_begin;
+    }
+#endif
+    flush(cur_tile);
+}
+
+// ===========================================================================
+// Fast kernel 2 ("hd"): lane = one row of 32 outputs, crossfaded IR formed on the fly
+// ===========================================================================
+// Each lane owns 32 consecutive, row-aligned outputs (both ears: 64 accumulators).  Its 128 taps
+// reach back over 5 input rows; for input row rho' (32 inputs, ONE crossfaded IR) the lane needs the
+// taps 32 rho' - 31 .. 32 rho' + 31 of that row's IR: a 32 x 32 Toeplitz block = 1024 FMAs per ear on
+// 8 + 63 LDS words of 128 bit.  LDS holds only the x window and, per chunk slot, the pair
+// (H_c, H_{c+1} - H_c) interleaved per tap as (h0_L, h0_R, d_L, d_R); the lane forms
+// g = h0 + al d (al = its row's crossfade weight) with one packed FMA per tap, 6 % on top of the FIR.
+// Nothing row-specific is staged, so a pass costs two barriers and a few dozen LDS stores, and with
+// ~38 KB of LDS four 2-wave workgroups share a CU.  Needs S a power of two (>= 32) and at most 12 chunk slots per tile (K >= 416).
+#define HD_NW 2                               // waves per workgroup
+#define HD_THREADS (64 * HD_NW)
+#define HD_TILE (2048 * HD_NW)                // outputs per tile
+#define HD_HALO (RT_SEG / 32)                 // input rows above a tile (4)
+#define HD_ROWS (HD_TILE / 32 + HD_HALO)      // rows in the x window (132)
+#define HD_XR (HD_ROWS + 1)                   // odd: conflict-free column-major image
+#define HD_NX ((HD_ROWS * 8 + HD_THREADS - 1) / HD_THREADS)     // float4 of x per thread (9)
+#define HD_SLOT (RT_SEG * 4 + 4)              // floats per chunk slot (+16 B: slots on distinct banks)
+#define HD_MAXSLOTS 12
+#define HD_X_FLOATS (8 * HD_XR * 4)
+
+__device__ __forceinline__ void hd_load_xrow(float (&xr)[32], const f32x4 *__restrict__ xrow) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4 v = xrow[c * HD_XR];
+        xr[4 * c] = v.x; xr[4 * c + 1] = v.y; xr[4 * c + 2] = v.z; xr[4 * c + 3] = v.w;
+    }
+}
+
+__device__ __forceinline__ void hd_load_octet(f32x4 (&hv)[8], const float *__restrict__ hdrow, int i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) hv[j] = *reinterpret_cast<const f32x4 *>(hdrow + (8 * i + j) * 4);
+}
+
+// one octet of taps (delta = 8 i + j - 32 = output index - input index) against the whole input row
+template <int I>
+__device__ __forceinline__ void hd_octet_fma(f32x2 (&acc)[32], const float (&xr)[32], const f32x4 (&hv)[8],
+                                              float al) {
+    f32x2 g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        g[j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al, al}, f32x2{hv[j].x, hv[j].y});
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        constexpr int dummy = 0;
+        const int delta = 8 * I + j - 32 + dummy;
+#pragma unroll
+        for (int o = 0; o < 32; ++o) {
+            const int a = o - delta;
+            if (a >= 0 && a < 32) fma2(acc[o], xr[a], g[j]);
+        }
+    }
+}
+
+// Row step with every octet I0..7 live: straight-line code, the next octet's LDS words are requested
+// before the current octet's FMAs (two register buffers).
+template <int I0>
+__device__ __forceinline__ void hd_row_step_full(f32x2 (&acc)[32], const f32x4 *__restrict__ xrow,
+                                                  const float *__restrict__ hdrow, float al) {
+    float xr[32];
+    f32x4 ha[8], hb[8];
+    hd_load_xrow(xr, xrow);
+    hd_load_octet(ha, hdrow, I0);
+    if constexpr (I0 <= 0) { hd_load_octet(hb, hdrow, 1); hd_octet_fma<0>(acc, xr, ha, al); hd_load_octet(ha, hdrow, 2); hd_octet_fma<1>(acc, xr, hb, al);
+                             hd_load_octet(hb, hdrow, 3); hd_octet_fma<2>(acc, xr, ha, al); hd_load_octet(ha, hdrow, 4); hd_octet_fma<3>(acc, xr, hb, al); }
+    hd_load_octet(hb, hdrow, 5);
+    hd_octet_fma<4>(acc, xr, ha, al);
+    hd_load_octet(ha, hdrow, 6);
+    hd_octet_fma<5>(acc, xr, hb, al);
+    hd_load_octet(hb, hdrow, 7);
+    hd_octet_fma<6>(acc, xr, ha, al);
+    hd_octet_fma<7>(acc, xr, hb, al);
+}
+
+// Row step with a run-time set of live octets (segments shorter than 128 taps, last row).
+__device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4 *__restrict__ xrow,
+                                                    const float *__restrict__ hdrow, float al,
+                                                    unsigned live_mask) {
+    float xr[32];
+    hd_load_xrow(xr, xrow);
+    f32x4 hv[8];
+#define HD_MASKED_OCTET(I)                          \
+    if (live_mask & (1u << I)) {                    \
+        hd_load_octet(hv, hdrow, I);                \
+        hd_octet_fma<I>(acc, xr, hv, al);           \
+    }
+    HD_MASKED_OCTET(0) HD_MASKED_OCTET(1) HD_MASKED_OCTET(2) HD_MASKED_OCTET(3)
+    HD_MASKED_OCTET(4) HD_MASKED_OCTET(5) HD_MASKED_OCTET(6) HD_MASKED_OCTET(7)
+#undef HD_MASKED_OCTET
+}
+
+__global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs A, int nslots) {
+    extern __shared__ f32x4 lds4[];
+    f32x4 *xs4 = lds4;                                       // [8][HD_XR] float4
+    float *hd = reinterpret_cast<float *>(lds4) + HD_X_FLOATS;   // [nslots][HD_SLOT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const long unit0 = (long)blockIdx.x * A.units_per_wg;
+    long unit1 = unit0 + A.units_per_wg;
+    if (unit1 > A.units_total) unit1 = A.units_total;
+    const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
+    const long n_pass = (unit1 - unit0) * nseg;
+    if (n_pass <= 0) return;
+
+    f32x2 acc[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+
+    const long first_tile = unit0 / A.n_src;
+    long cur_tile = first_tile;
+    float *slab_wg = A.slab + (long)blockIdx.x * A.parts_per_wg * 2 * HD_TILE;
+    const float invK = 1.0f / (float)A.K;
+
+    auto flush = [&](long tile) {
+        float *dst = slab_wg + (tile - first_tile) * 2 * HD_TILE + 2048 * wv + 32 * lane;
+        f32x4 *l4 = reinterpret_cast<f32x4 *>(dst);
+        f32x4 *r4 = reinterpret_cast<f32x4 *>(dst + HD_TILE);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            l4[i] = f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x};
+            r4[i] = f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y};
+        }
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+    };
+
+    for (long pid = 0; pid < n_pass; ++pid) {
+        const long unit = unit0 + pid / nseg;
+        const int seg0 = (int)(pid % nseg) * RT_SEG;
         const long tile = unit / A.n_src;
         const int s = (int)(unit - tile * A.n_src);
+        const int Lseg = A.Lp - seg0 < RT_SEG ? A.Lp - seg0 : RT_SEG;
+        const int halo = (Lseg + 31) >> 5;                   // input rows above the tile that matter
+        const long xbase = tile * HD_TILE - seg0 - 32L * halo;   // first input sample in LDS (mult. of 32)
+        const int nrows = HD_TILE / 32 + halo;
+        long cf = xbase / A.K;                               // floor division, consistent across 0
+        if (cf * A.K > xbase) --cf;
+        const int c0 = (int)cf;
+        const int mo0 = (int)(xbase - cf * A.K);
         if (tile != cur_tile) {
             flush(cur_tile);
             cur_tile = tile;
         }
-        const long n0 = tile * RT_TILE;
+
+        // ---- global -> registers: x window (all threads), chunk IRs of tap `tid` (threads < Lseg)
         const float *xsrc = A.x + (long)s * A.x_stride;
-        const float *Hs = A.H + (long)s * (A.n_chunks + 1) * 2 * A.L;
-
-        for (int seg0 = 0; seg0 < A.Lp; seg0 += RT_SEG) {
-            const int Lseg = A.Lp - seg0 < RT_SEG ? A.Lp - seg0 : RT_SEG;   // multiple of 8
-            const int Q = Lseg >> 3;                                        // 8-tap groups
-            const long top = n0 - seg0;                                     // multiple of 32
-            const long rho0 = (top - Lseg) >> 5;                            // floor: first row
-            const long xbase = rho0 << 5;
-            const int nrows = (int)((top >> 5) + RT_TILE / 32 - rho0);      // <= RT_ROWS
-
-            __syncthreads();            // previous pass has finished reading LDS
-
-            // ---- stage x: column-major image, xs4[c][r] = x[xbase + 32 r + 4 c .. +3]
-            for (int i4 = tid; i4 < nrows * 8; i4 += RT_THREADS) {
-                const long m = xbase + 4L * i4;
-                f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m >= 0 && m < A.T_in) v = *reinterpret_cast<const f32x4 *>(xsrc + m);
-                xs4[(i4 & 7) * RT_XR + (i4 >> 3)] = v;
-            }
-
-            // ---- stage the crossfaded IR of every row: thread = (ear, tap)
-            if (tid < 2 * Lseg) {
-                const int e = tid >= Lseg ? 1 : 0;
-                const int kap = tid - e * Lseg;
-                const int k = seg0 + kap;
-                const bool live = k < A.L;
-                const float *Hk = Hs + e * A.L + (live ? k : 0);
-                // chunk / subchunk position of the first row (clamped into the signal)
-                long m_r = xbase;
-                long mc = m_r < 0 ? 0 : (m_r >= A.T_in ? A.T_in - 32 : m_r);
-                int c = (int)(mc / A.K);
-                int mo = (int)(mc - (long)c * A.K);         // offset inside the chunk
-                int so = mo % A.S;                          // offset inside the subchunk
-                float h0 = live ? Hk[(long)c * 2 * A.L] : 0.f;
-                float h1 = live ? Hk[(long)(c + 1) * 2 * A.L] : 0.f;
-                const float invK = 1.0f / (float)A.K;
-                float *gdst = gs + kap * 2 + e;
-                for (int r = 0; r < nrows; ++r) {
-                    const float al = (float)(mo - so) * invK;               // apply_hrtf.py:442
-                    gdst[r * RT_RS] = (1.0f - al) * h0 + al * h1;           // :443
-                    if (m_r >= 0 && m_r + 32 < A.T_in) {    // advance inside the signal only
-                        mo += 32;
-                        so += 32;
-                        if (so >= A.S) so = 0;
-                        if (mo >= A.K) {
-                            mo = 0;
-                            ++c;
-                            h0 = h1;
-                            h1 = live ? Hk[(long)(c + 1) * 2 * A.L] : 0.f;
-                        }
-                    }
-                    m_r += 32;
+        f32x4 xv[HD_NX];
+#pragma unroll
+        for (int j = 0; j < HD_NX; ++j) {
+            long m = xbase + 4L * (tid + j * HD_THREADS);
+            m = m < 0 ? 0 : (m > A.T_in - 4 ? A.T_in - 4 : m);
+            xv[j] = *reinterpret_cast<const f32x4 *>(xsrc + m);
+        }
+        float hl[HD_MAXSLOTS + 1], hr[HD_MAXSLOTS + 1];
+        {
+            int k = seg0 + tid;
+            if (k > A.L - 1) k = A.L - 1;
+            const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
+#pragma unroll
+            for (int j = 0; j <= HD_MAXSLOTS; ++j) {
+                if (j <= nslots) {                           // uniform
+                    const float *p = Hk + (long)clampi(c0 + j, 0, A.n_chunks) * 2 * A.L;
+                    hl[j] = p[0];
+                    hr[j] = p[A.L];
                 }
             }
-            __syncthreads();
+        }
 
-            // ---- FIR: blocks q = 0..Q, inputs [n_t - seg0 - 8q, +8), taps seg0 + 8q-7 .. 8q+7
-            const int off0 = (int)(top - xbase) + 8 * u;
-            Win wa, wb;
-            float x8[8];
-            {
-                const int r = lane + (off0 >> 5), cp = (off0 & 31) >> 3;
-                load_x8(x8, xs4, cp, r);
-                win_load(wa, gs + r * RT_RS);
-                fir_first(acc, x8, wa);
-            }
-            // middle blocks: window (old,new) ping-pongs between wa and wb
-            auto middle = [&](int q, Win &old, Win &nw) {
-                const int off = off0 - 8 * q;
-                const int r = lane + (off >> 5), cp = (off & 31) >> 3;
-                const float *grow = gs + r * RT_RS + 16 * q;
-                load_x8(x8, xs4, cp, r);
-                win_load(nw, grow);
-                if (cp == 3) win_load(old, grow - 16);      // crossed into the previous row
-                fir_mid(acc, x8, old, nw);
-            };
-            auto last = [&](int q, Win &old) {
-                const int off = off0 - 8 * q;
-                const int r = lane + (off >> 5), cp = (off & 31) >> 3;
-                load_x8(x8, xs4, cp, r);
-                if (cp == 3) win_load(old, gs + r * RT_RS + 16 * q - 16);
-                fir_last(acc, x8, old);
-            };
-            int q = 1;
-            for (; q + 1 < Q; q += 2) {
-                middle(q, wa, wb);
-                middle(q + 1, wb, wa);
-            }
-            if (q < Q) {
-                middle(q, wa, wb);
-                last(q + 1, wb);
-            } else {
-                last(q, wa);
+        __syncthreads();                                     // previous pass has finished reading LDS
+#pragma unroll
+        for (int j = 0; j < HD_NX; ++j) {
+            const int i4 = tid + j * HD_THREADS;
+            const long m = xbase + 4L * i4;
+            f32x4 v = xv[j];
+            v = (m >= 0 && m < A.T_in) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i4 < nrows * 8) xs4[(i4 & 7) * HD_XR + (i4 >> 3)] = v;
+        }
+        if (tid < Lseg) {
+            const float live = seg0 + tid < A.L ? 1.0f : 0.0f;   // taps >= L read as zero
+            f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + tid;
+#pragma unroll
+            for (int j = 0; j < HD_MAXSLOTS; ++j) {
+                if (j < nslots)
+                    dst[j * (HD_SLOT / 4)] = f32x4{hl[j], hr[j], hl[j + 1] - hl[j], hr[j + 1] - hr[j]} * live;
             }
         }
+        __syncthreads();
+
+        // ---- FIR: input rows rho' = 0..halo above/at the lane's output row
+        const int row_out = 64 * wv + lane + halo;           // window row holding the lane's outputs
+        int pos = mo0 + 32 * row_out;
+        int sl = pos / A.K;                                  // chunk slot of that row
+        int m_in = pos - sl * A.K;                           // offset of the row inside its chunk
+        const f32x4 *xrow = xs4 + row_out;
+        // octet i of row step rp holds taps 32 rp - 32 + 8 i .. +7 (relative to seg0); live iff in [0, Lseg)
+        auto mask_of = [&](int rp) {
+            unsigned mk = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t0 = 32 * rp - 32 + 8 * i;
+                if (t0 >= 0 && t0 < Lseg) mk |= 1u << i;
+            }
+            return mk;
+        };
+        auto step_setup = [&](int rp, float &al, const float *&hdrow) {
+            al = (float)(m_in - (m_in & (A.S - 1))) * invK;                  // S is a power of two here
+            hdrow = hd + sl * HD_SLOT + (32 * rp - 32) * 4;
+        };
+        auto step_done = [&]() {
+            xrow -= 1;
+            m_in -= 32;
+            if (m_in < 0) {
+                m_in += A.K;
+                sl -= 1;
+            }
+        };
+        for (int rp = 0; rp <= halo; ++rp) {
+            float al;
+            const float *hdrow;
+            step_setup(rp, al, hdrow);
+            hd_row_step_masked(acc, xrow, hdrow, al, mask_of(rp));
+            step_done();
+        }
     }
-    if (unit1 > unit0) flush(cur_tile);
+    flush(cur_tile);
 }
 
 // ---------------------------------------------------------------------------
@@ -288,17 +667,17 @@ __global__ __launch_bounds__(256) void bas_render_generic_kernel(const float *__
 // ---------------------------------------------------------------------------
 // Slab reduction (fixed order => deterministic) + optional fused max|y|
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__restrict__ slab, int n_src,
-                                                                int units_per_wg, int parts_per_wg,
-                                                                int n_wg, long T_out,
+__global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__restrict__ slab, int tile_len,
+                                                                int n_src, int units_per_wg,
+                                                                int parts_per_wg, int n_wg, long T_out,
                                                                 float *__restrict__ y, int accumulate,
                                                                 unsigned int *peak_bits) {
     float lmax = 0.f;
     const long n4 = (T_out + 3) / 4;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
         const long n = i * 4;
-        const long tile = n / RT_TILE;
-        const int off = (int)(n - tile * RT_TILE);
+        const long tile = n / tile_len;
+        const int off = (int)(n - tile * tile_len);
         const long ulo = tile * n_src, uhi = ulo + n_src - 1;
         const int wlo = (int)(ulo / units_per_wg);
         int whi = (int)(uhi / units_per_wg);
@@ -306,9 +685,9 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__res
         f32x4 sl = f32x4{0.f, 0.f, 0.f, 0.f}, sr = sl;
         for (int w = wlo; w <= whi; ++w) {
             const long first_tile = ((long)w * units_per_wg) / n_src;
-            const float *p = slab + (((long)w * parts_per_wg + (tile - first_tile)) * 2) * RT_TILE + off;
+            const float *p = slab + (((long)w * parts_per_wg + (tile - first_tile)) * 2) * tile_len + off;
             sl += *reinterpret_cast<const f32x4 *>(p);
-            sr += *reinterpret_cast<const f32x4 *>(p + RT_TILE);
+            sr += *reinterpret_cast<const f32x4 *>(p + tile_len);
         }
         float vl[4] = {sl.x, sl.y, sl.z, sl.w}, vr[4] = {sr.x, sr.y, sr.z, sr.w};
 #pragma unroll
@@ -384,33 +763,77 @@ static int device_cus() {
     return cus;
 }
 
+enum { KIND_GENERIC = 0, KIND_ROWS32 = 1, KIND_HD = 2 };
+
 struct RenderPlan {
-    bool fast;
+    int kind;
+    int tile;                  // outputs per tile
     long n_tiles, units_total;
     int n_wg, units_per_wg, parts_per_wg;
-    size_t slab_bytes;
+    int hd_slots;              // chunk slots of the hd kernel
+    size_t lds_bytes, slab_bytes;
 };
 
+// Which kernel renders (n_src, T_in, K, S, L), and how the (tile, source) work units are dealt to
+// workgroups: equal contiguous shares, so every workgroup finishes at the same time.
 static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool aligned) {
     RenderPlan p = {};
-    p.fast = aligned && n_src > 0 && (S % 32 == 0);
-    if (!p.fast) return p;
+    p.kind = KIND_GENERIC;
+    if (!(aligned && n_src > 0 && T_in > 0 && S % 32 == 0)) return p;
+    const bool s_pow2 = (S & (S - 1)) == 0;
+    const int hd_slots = (K - 32 + 32 * (HD_ROWS - 1)) / K + 1;
+    const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
+    int kind = (s_pow2 && hd_slots <= HD_MAXSLOTS) ? KIND_HD : KIND_ROWS32;
+    if (force && !strcmp(force, "rows32")) kind = KIND_ROWS32;
+    if (force && !strcmp(force, "generic")) return p;
+    if (kind == KIND_ROWS32 && L % 2 != 0) return p;         // rows32 loads tap pairs
+    long wg_per_cu;
+    if (kind == KIND_HD) {
+        p.tile = HD_TILE;
+        p.hd_slots = hd_slots;
+        p.lds_bytes = (size_t)(HD_X_FLOATS + hd_slots * HD_SLOT) * sizeof(float);
+        wg_per_cu = (long)(160 * 1024 / p.lds_bytes);
+        if (wg_per_cu > 4) wg_per_cu = 4;
+        if (wg_per_cu < 1) wg_per_cu = 1;
+    } else {
+        p.tile = RT_TILE;
+        p.lds_bytes = RT_LDS_BYTES;
+        wg_per_cu = 2;
+    }
+    p.kind = kind;
     const long T_out = T_in + L - 1;
-    p.n_tiles = (T_out + RT_TILE - 1) / RT_TILE;
+    p.n_tiles = (T_out + p.tile - 1) / p.tile;
     p.units_total = p.n_tiles * n_src;
-    long slots = 2L * device_cus();
+    long slots = wg_per_cu * device_cus();
     long wg = p.units_total < slots ? p.units_total : slots;
     p.units_per_wg = (int)((p.units_total + wg - 1) / wg);
     p.n_wg = (int)((p.units_total + p.units_per_wg - 1) / p.units_per_wg);
     p.parts_per_wg = (p.units_per_wg + n_src - 2) / n_src + 1;
-    p.slab_bytes = (size_t)p.n_wg * p.parts_per_wg * 2 * RT_TILE * sizeof(float);
+    p.slab_bytes = (size_t)p.n_wg * p.parts_per_wg * 2 * p.tile * sizeof(float);
     return p;
 }
 
 extern "C" size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S, int L) {
     if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return 16;
+    // the kernel is chosen at launch time (pointer alignment, diagnostics override): both fast kernels
+    // use the same slab formula, so size for the larger tile count of the two
     RenderPlan p = plan_render(n_src, T_in, K, S, L, true);
-    return (p.fast ? p.slab_bytes : 0) + 16;
+    size_t need = p.slab_bytes;
+    if (p.kind == KIND_HD && L % 2 == 0) {
+        RenderPlan q = p;
+        const long T_out = T_in + L - 1;
+        q.tile = RT_TILE;
+        q.n_tiles = (T_out + RT_TILE - 1) / RT_TILE;
+        q.units_total = q.n_tiles * n_src;
+        long slots = 2L * device_cus();
+        long wg = q.units_total < slots ? q.units_total : slots;
+        q.units_per_wg = (int)((q.units_total + wg - 1) / wg);
+        q.n_wg = (int)((q.units_total + q.units_per_wg - 1) / q.units_per_wg);
+        q.parts_per_wg = (q.units_per_wg + n_src - 2) / n_src + 1;
+        size_t alt = (size_t)q.n_wg * q.parts_per_wg * 2 * RT_TILE * sizeof(float);
+        if (alt > need) need = alt;
+    }
+    return need + 16;
 }
 
 static int render_mix_impl(const float *x, long x_stride, const float *H, int n_src, long T_in, int K, int S,
@@ -436,10 +859,10 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     }
     const int n_chunks = (int)(T_in / K);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (x_stride % 4 == 0) &&
-                         (reinterpret_cast<uintptr_t>(ws) % 16 == 0);
+                         (reinterpret_cast<uintptr_t>(ws) % 16 == 0) && (reinterpret_cast<uintptr_t>(H) % 8 == 0);
     const int live_src = T_in == 0 ? 0 : n_src;
     RenderPlan p = plan_render(live_src, T_in, K, S, L, aligned);
-    if (!p.fast) {
+    if (p.kind == KIND_GENERIC) {
         if (ev_begin) (void)hipEventRecord(ev_begin, st);
         hipLaunchKernelGGL(bas_render_generic_kernel, dim3(grid_for(T_out, 8192)), dim3(256), 0, st, x, x_stride,
                            H, live_src, T_in, K, S, L, n_chunks, T_out, y, accumulate, peak_bits);
@@ -453,16 +876,21 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     A.K = K; A.S = S; A.L = L; A.Lp = (L + 7) & ~7; A.n_chunks = n_chunks;
     A.units_total = p.units_total; A.units_per_wg = p.units_per_wg; A.parts_per_wg = p.parts_per_wg;
     A.slab = reinterpret_cast<float *>(ws);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bas_render_rows32_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, RT_LDS_BYTES);
+    { const char *d = getenv("BAS_DEBUG_FLAGS"); A.dbg = d ? atoi(d) : 0; }
+    const void *fn = p.kind == KIND_HD ? reinterpret_cast<const void *>(bas_render_hd_kernel)
+                                        : reinterpret_cast<const void *>(bas_render_rows32_kernel);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
-    hipLaunchKernelGGL(bas_render_rows32_kernel, dim3(p.n_wg), dim3(RT_THREADS), RT_LDS_BYTES, st, A);
+    if (p.kind == KIND_HD)
+        hipLaunchKernelGGL(bas_render_hd_kernel, dim3(p.n_wg), dim3(HD_THREADS), p.lds_bytes, st, A, p.hd_slots);
+    else
+        hipLaunchKernelGGL(bas_render_rows32_kernel, dim3(p.n_wg), dim3(RT_THREADS), p.lds_bytes, st, A);
     if (ev_end) (void)hipEventRecord(ev_end, st);
-    int rc = bas_check_launch("bas_render_mix_f32(rows32)");
+    int rc = bas_check_launch(p.kind == KIND_HD ? "bas_render_mix_f32(hd)" : "bas_render_mix_f32(rows32)");
     if (rc) return rc;
     hipLaunchKernelGGL(bas_slab_reduce_kernel, dim3(grid_for((T_out + 3) / 4, 2048)), dim3(256), 0, st,
-                       A.slab, live_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
+                       A.slab, p.tile, live_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
                        peak_bits);
     return bas_check_launch("bas_render_mix_f32(reduce)");
 }
@@ -521,3 +949,9 @@ extern "C" int bas_mix_partials_f32(const float *parts, int n_parts, long part_s
                        part_stride, n, y, reinterpret_cast<unsigned int *>(peak));
     return bas_check_launch("bas_mix_partials_f32");
 }
+
+#ifdef BAS_STAMPS
+extern "C" int bas_debug_read_stamps(unsigned long long *host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bas_dbg_stamps), count * sizeof(unsigned long long));
+}
+#endif
