@@ -177,13 +177,14 @@ def main():
     y = torch.empty((2, t_out), dtype=torch.float32, device=dev)
     ws = torch.empty((_hip.lib().bas_render_workspace_bytes(n_src, in_length, k, s, l),), dtype=torch.uint8,
                      device=dev)
+    ws_i = torch.empty((_hip.lib().bas_interp2d_workspace_bytes(n_src * n_q),), dtype=torch.uint8, device=dev)
     parts = torch.empty((world, 2, t_out), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
     y_final = torch.empty((2, t_out), dtype=torch.float32, device=dev)
     peak = torch.empty((1,), dtype=torch.float32, device=dev)
     ev = HipEvents(args.steps)
 
     def step(i_event=None):
-        bas.interpolate_2d_params(tbl, idx, w, out=H, validate=False)
+        bas.interpolate_2d_params(tbl, idx, w, out=H, validate=False, ws=ws_i)
         events = None if i_event is None else ev.pairs[i_event]
         _, pk = bas.apply_hrtf.render_device(x, k, s, H.view(n_src, n_q, 2, l), l, normalize="none", out=y,
                                              events=events, ws=ws)

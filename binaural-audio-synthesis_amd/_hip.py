@@ -16,12 +16,14 @@ _c_int, _c_long, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_si
 SIGNATURES = {
     "bas_version": (_c_int, []),
     "bas_last_error": (ctypes.c_char_p, []),
+    "bas_table_packed_floats": (_c_size_t, [_c_int, _c_int, _c_int]),
     "bas_table_pack_f32": (_c_int, [_c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "bas_delay_signal_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "bas_ring_interp_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                      _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "bas_interp2d_workspace_bytes": (_c_size_t, [_c_int]),
     "bas_interp2d_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
-                                  _c_int, _c_void_p, _c_void_p]),
+                                  _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "bas_render_workspace_bytes": (_c_size_t, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_mix_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_int,
                                     _c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),

@@ -48,7 +48,8 @@ class irs_and_delaydiffs:
         self.irs_left, self.irs_right = irs[0], irs[1]                      # :43-44
         self.diffs = torch.from_numpy(np.stack([dl, dr])).to(device)        # [2][ndir][ndir] f64
         self.diffs_left, self.diffs_right = self.diffs[0], self.diffs[1]    # :40-41
-        self.packed = torch.empty_like(irs)                                 # [2][ndir][U][L]
+        n_packed = _hip.lib().bas_table_packed_floats(self.ndir, self.M, self.upsampling)
+        self.packed = torch.empty((n_packed,), dtype=torch.float32, device=device)   # [2][ndir][U][1+L]
         _hip.call("bas_table_pack_f32", _hip.ptr(irs), self.ndir, self.M, self.upsampling,
                   _hip.ptr(self.packed), _hip.current_stream(device))
 
@@ -123,7 +124,7 @@ def delay_compensated_interpolation_with_delaydiff(irs_and_delaydiffs, before: i
 # --------------------------------------------------------------------------
 # a6
 # --------------------------------------------------------------------------
-def interpolate_2d_params(tbl, idx, w, out=None, validate=True):
+def interpolate_2d_params(tbl, idx, w, out=None, validate=True, ws=None):
     """Batched table arithmetic of interpolate_2d (apply_hrtf.py:219-279) for
     precomputed parameters: idx int32 [n,4], w float64 [n,3] (numpy or device
     tensors).  Returns a device tensor [n, 2, L] float32 (`out` if given).
@@ -139,8 +140,11 @@ def interpolate_2d_params(tbl, idx, w, out=None, validate=True):
     if validate and n and (int(idx_t.min()) < 0 or int(idx_t.max()) >= tbl.ndir):
         raise IndexError("HRTF database index out of range")
     H = out if out is not None else torch.empty((n, 2, tbl.L), dtype=torch.float32, device=dev)
+    ws_bytes = _hip.lib().bas_interp2d_workspace_bytes(n)
+    if ws is None or ws.numel() < ws_bytes:
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     _hip.call("bas_interp2d_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(idx_t), _hip.ptr(w_t), n,
-              tbl.ndir, tbl.L, tbl.upsampling, _hip.ptr(H), _hip.current_stream(dev))
+              tbl.ndir, tbl.L, tbl.upsampling, _hip.ptr(H), _hip.ptr(ws), ws.numel(), _hip.current_stream(dev))
     return H
 
 

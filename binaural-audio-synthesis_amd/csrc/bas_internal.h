@@ -35,3 +35,24 @@ __device__ __forceinline__ void bas_split_shift(double s, long long &b, float &f
     b = (long long)fl;
     f = (float)(s - fl);
 }
+
+// s = b + f with b = floor(s), f in [0,1); returns b reduced into [0, M) (all in binary64, exact for
+// |s| < 2^52) so that every later position sum stays in cheap 32-bit arithmetic.
+__device__ __forceinline__ int bas_split_shift_mod(double s, int M, float &f) {
+    if (!(s == s)) s = 0.0;                       // NaN shift: treat as 0 (reference would raise)
+    if (s > 1e15) s = 1e15;
+    if (s < -1e15) s = -1e15;
+    const double fl = floor(s);
+    f = (float)(s - fl);
+    const double r = fl - (double)M * floor(fl / (double)M);
+    int b = (int)r;
+    if (b >= M) b -= M;                            // guards the rounding of fl / M
+    if (b < 0) b += M;
+    return b;
+}
+
+// (a - b) mod M for a, b in [0, M)
+__device__ __forceinline__ int bas_submod(int a, int b, int M) {
+    const int c = a - b;
+    return c < 0 ? c + M : c;
+}

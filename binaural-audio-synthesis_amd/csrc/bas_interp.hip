@@ -17,22 +17,35 @@
 // positions -> R_b at 3, R_t at 2 -> B_b at 4, B_t at 3 -> 4+5+3+4 = 16 table
 // samples.  All positions are (m*U + c) mod M with c uniform over the query, so in
 // the phase-plane layout packed[e][p][c mod U][.] every one of the 16 reads is a
-// contiguous run across the lanes (lane = tap m).
+// contiguous run across the lanes (a lane owns two adjacent taps and reads them with one
+// 8-byte load).  Each plane carries a guard float at either end (front: copy of its last
+// sample, back: copy of its first), so "one plane-sample earlier" and "the next tap" never
+// need a wrap test: the reads of one set share a single per-lane offset and differ only in
+// a wave-uniform base.  All blends are linear with query-uniform coefficients, hence
+//     h[m] = sum_k W_k * sample_k(m)
+// with the 16 weights W_k folded once per (query, ear) in binary64.
 #include "bas_internal.h"
 
 // ---------------------------------------------------------------------------
-// a1: [2][ndir][M] -> [2][ndir][U][L]
+// a1: [2][ndir][M] -> [2][ndir][U][L + 2]   (plane = [last sample][L samples][first sample])
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bas_pack_kernel(const float *__restrict__ irs, long rows,
                                                          int M, int U, int L,
                                                          float *__restrict__ packed) {
-    long total = rows * (long)M;
+    const int LP = L + 2;
+    long total = rows * (long)U * LP;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
-        long row = i / M;
-        int j = (int)(i - row * M);            // destination index inside the row: ph*L + idx
-        int ph = j / L, idx = j - ph * L;
+        long row = i / ((long)U * LP);
+        int j = (int)(i - row * U * LP);
+        int ph = j / LP, g = j - ph * LP;          // g = 0 and g = L + 1 are the guards
+        int idx = g == 0 ? L - 1 : (g == L + 1 ? 0 : g - 1);
         packed[i] = irs[row * M + (long)idx * U + ph];
     }
+}
+
+extern "C" size_t bas_table_packed_floats(int ndir, int M, int U) {
+    if (ndir <= 0 || U <= 0 || M <= 0 || M % U) return 0;
+    return (size_t)2 * ndir * U * (M / U + 2);
 }
 
 extern "C" int bas_table_pack_f32(const float *irs, int ndir, int M, int U, float *packed,
@@ -41,7 +54,7 @@ extern "C" int bas_table_pack_f32(const float *irs, int ndir, int M, int U, floa
     BAS_REQUIRE(ndir > 0 && U > 0 && M > 0 && M % U == 0, BAS_E_SHAPE,
                 "bas_table_pack_f32: need ndir>0, U>0, M>0, M %% U == 0 (ndir=%d M=%d U=%d)", ndir, M, U);
     long rows = 2L * ndir;
-    long total = rows * M;
+    long total = rows * U * (M / U + 2);
     int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(bas_pack_kernel, dim3(grid), dim3(256), 0, bas_stream(stream), irs, rows, M, U,
                        M / U, packed);
@@ -116,7 +129,7 @@ __device__ __forceinline__ float tab_read(const float *__restrict__ packed, int 
     }
     int idx = m + o;                 // m < L, o < L
     if (idx >= L) idx -= L;
-    return packed[row + ph * L + idx];
+    return packed[row + ph * (L + 2) + 1 + idx];
 }
 
 // R = S(B, al D) at the positions (c_p - j), j = 0..NR-1, relative to the lane's tap
@@ -139,20 +152,18 @@ __device__ __forceinline__ void ring_eval(const float *__restrict__ packed, cons
 // Fills the ring part of a plan.  `c_out` is the offset (mod M) at which R itself is
 // wanted for j = 0.  Returns al*D (upsampled samples) through s2.
 __device__ __forceinline__ void ring_plan(RingPlan &rp, const double *__restrict__ d, int e, int ndir,
-                                           int p, int q, double al, int L, int U, long long c_out,
+                                           int p, int q, double al, int L, int U, int c_out,
                                            double &s2) {
     int M = L * U;
     double D = (double)U * d[(long)p * ndir + q];                   // apply_hrtf.py:82-83
     s2 = al * D;                                                    // :94-95
-    long long b1, b2;
     float f1, f2;
-    bas_split_shift(-D, b1, f1);                                    // :86-87
-    bas_split_shift(s2, b2, f2);                                    // :98-99
-    rp.row_p = (e * ndir + p) * M;
-    rp.row_q = (e * ndir + q) * M;
-    long long cB = c_out - b2;                                      // B is read at (c_out - j) - b2 (-1)
-    rp.c_p = bas_pmod(cB, M);
-    rp.c_q = bas_pmod(cB - b1, M);
+    const int b1 = bas_split_shift_mod(-D, M, f1);                  // :86-87
+    const int b2 = bas_split_shift_mod(s2, M, f2);                  // :98-99
+    rp.row_p = (e * ndir + p) * (M + 2 * U);   // plane stride L + 2
+    rp.row_q = (e * ndir + q) * (M + 2 * U);
+    rp.c_p = bas_submod(c_out, b2, M);                              // B is read at (c_out - j) - b2 (-1)
+    rp.c_q = bas_submod(rp.c_p, b1, M);
     rp.f1 = f1;
     rp.f2 = f2;
     rp.al = (float)al;
@@ -161,84 +172,191 @@ __device__ __forceinline__ void ring_plan(RingPlan &rp, const double *__restrict
 // ---------------------------------------------------------------------------
 // a6: batched interpolate_2d
 // ---------------------------------------------------------------------------
+// Phase 1 (32 threads): one thread per (query, ear) folds indices, weights and delay differences
+// into a plan: for each of the 4 read sets (bottom T_q x5, bottom T_p x4, top T_q x4, top T_p x3)
+// the first read's plane address and plane offset, plus the 16 weights.
+// Phase 2: wave w handles ear w&1 of every second query of the workgroup.  The plan is
+// wave-uniform and lives in SGPRs; per output tap a lane computes 4 wrapped offsets (one per set),
+// 16 loads off scalar bases and 16 FMAs with scalar weights.
 #define BAS_QB 16      // queries per workgroup
 
-template <bool POW2>
-__global__ __launch_bounds__(256) void bas_interp2d_kernel(const float *__restrict__ packed,
-                                                             const double *__restrict__ diffs,
-                                                             const int32_t *__restrict__ idx,
-                                                             const double *__restrict__ w, int n,
-                                                             int ndir, int L, int U, int ush,
-                                                             float *__restrict__ H) {
-    __shared__ EarPlan plans[BAS_QB * 2];
-    const int q0 = blockIdx.x * BAS_QB;
-    const int nq = n - q0 < BAS_QB ? n - q0 : BAS_QB;
-    const int M = L * U;
+struct SetPlan {
+    int base;          // float index of plane ph0's sample 0 in `packed` (guard is at base - 1)
+    int ph0;           // phase of read j = 0; reads j <= ph0 stay in plane ph0 - j at offset o,
+    int o;             // reads j > ph0 continue in plane ph0 - j + U one sample earlier
+    int pad;
+};
 
-    if ((int)threadIdx.x < nq * 2) {
-        const int ql = threadIdx.x >> 1, e = threadIdx.x & 1;
-        const long q = q0 + ql;
-        const int pt = clamp_dir(idx[4 * q + 0], ndir), qt = clamp_dir(idx[4 * q + 1], ndir);
-        const int pb = clamp_dir(idx[4 * q + 2], ndir), qb = clamp_dir(idx[4 * q + 3], ndir);
-        const double at = w[3 * q + 0], ab = w[3 * q + 1], a = w[3 * q + 2];
-        const double *d = diffs + (long)e * ndir * ndir;
-        // delays of the two ring interpolations in non-upsampled samples (apply_hrtf.py:106)
-        const double dt = (at * ((double)U * d[(long)pt * ndir + qt])) / (double)U;
-        const double db = (ab * ((double)U * d[(long)pb * ndir + qb])) / (double)U;
-        const double dv = (double)U * (-dt + d[(long)pt * ndir + pb] + db);     // :246-252
-        long long b3, b4;
-        float f3, f4;
-        bas_split_shift(-dv, b3, f3);                                           // :254-255
-        bas_split_shift((1.0 - a) * dv, b4, f4);                                // :272-277
-        EarPlan &pl = plans[threadIdx.x];
-        double s2;
-        // C is read at -b4 - j; R_t at the same offsets; R_b at (-b4 - b3) - j
-        ring_plan(pl.top, d, e, ndir, pt, qt, at, L, U, -b4, s2);
-        ring_plan(pl.bot, d, e, ndir, pb, qb, ab, L, U, -b4 - b3, s2);
-        pl.f3 = f3;
-        pl.f4 = f4;
-        pl.a = (float)a;
+struct EarPlanW {
+    SetPlan set[4];
+    float w[16];       // same order as the sets: 5 + 4 + 4 + 3
+};
+
+__device__ __forceinline__ void make_set(SetPlan &sp, int row, int c, int L, int U) {
+    const int o = c / U, ph = c - o * U;           // c in [0, M)
+    sp.base = row + ph * (L + 2) + 1;
+    sp.ph0 = ph;
+    sp.o = o;
+    sp.pad = 0;
+}
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float rflf(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
+// acc += sum_j w[j] * packed[plane(j)][wrap(m + o) (- 1 after the phase wrapped) + {0, 1}]
+template <int N>
+__device__ __forceinline__ f32x2 set_dot(const float *__restrict__ packed, int base, int ph0, int o,
+                                          const float *w, int m, int L, int U, f32x2 acc) {
+    const unsigned idx = (unsigned)(m + o);                  // m < L, o < L
+    const unsigned wr = idx - (unsigned)L;
+    const unsigned off = idx < wr ? idx : wr;                // idx >= L ? idx - L : idx
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        // wave-uniform plane base; j > ph0: plane + U, one sample earlier (the guards make -1 and +1 safe)
+        const int pb = j <= ph0 ? base - j * (L + 2) : base + (U - j) * (L + 2) - 1;
+        const f32x2 v = *reinterpret_cast<const f32x2_a4 *>(packed + pb + off);
+        acc = __builtin_elementwise_fma(v, f32x2{w[j], w[j]}, acc);
     }
-    __syncthreads();
+    return acc;
+}
 
-    for (int i = threadIdx.x; i < 2 * L; i += 256) {
-        const int e = i >= L ? 1 : 0;
-        const int m = i - e * L;
-        for (int ql = 0; ql < nq; ++ql) {
-            const EarPlan &pl = plans[ql * 2 + e];
-            float rb[3], rt[2];
-            ring_eval<POW2, 3>(packed, pl.bot, m, L, U, ush, M, rb);
-            ring_eval<POW2, 2>(packed, pl.top, m, L, U, ush, M, rt);
-            float c0 = (1.0f - pl.a) * ((1.0f - pl.f3) * rb[0] + pl.f3 * rb[1]) + pl.a * rt[0];   // :268-269
-            float c1 = (1.0f - pl.a) * ((1.0f - pl.f3) * rb[1] + pl.f3 * rb[2]) + pl.a * rt[1];
-            H[(long)(q0 + ql) * 2 * L + i] = (1.0f - pl.f4) * c0 + pl.f4 * c1;                     // :276-277
+// plan kernel: one thread per (query, ear)
+__global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__restrict__ diffs,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  const double *__restrict__ w, int n,
+                                                                  int ndir, int L, int U,
+                                                                  EarPlanW *__restrict__ plans) {
+    const long t = blockIdx.x * 256L + threadIdx.x;
+    if (t >= 2L * n) return;
+    const long q = t >> 1;
+    const int e = (int)(t & 1);
+    const int M = L * U;
+    const int pt = clamp_dir(idx[4 * q + 0], ndir), qt = clamp_dir(idx[4 * q + 1], ndir);
+    const int pb = clamp_dir(idx[4 * q + 2], ndir), qb = clamp_dir(idx[4 * q + 3], ndir);
+    const double at = w[3 * q + 0], ab = w[3 * q + 1], a = w[3 * q + 2];
+    const double *d = diffs + (long)e * ndir * ndir;
+    // delays of the two ring interpolations in non-upsampled samples (apply_hrtf.py:106)
+    const double dt = (at * ((double)U * d[(long)pt * ndir + qt])) / (double)U;
+    const double db = (ab * ((double)U * d[(long)pb * ndir + qb])) / (double)U;
+    const double dv = (double)U * (-dt + d[(long)pt * ndir + pb] + db);         // :246-252
+    float f3, f4;
+    const int b3 = bas_split_shift_mod(-dv, M, f3);                             // :254-255
+    const int b4 = bas_split_shift_mod((1.0 - a) * dv, M, f4);                  // :272-277
+    RingPlan top, bot;
+    double s2;
+    // C is read at -b4 - j; R_t at the same offsets; R_b at (-b4 - b3) - j
+    const int c_top = bas_submod(0, b4, M);
+    ring_plan(top, d, e, ndir, pt, qt, at, L, U, c_top, s2);
+    ring_plan(bot, d, e, ndir, pb, qb, ab, L, U, bas_submod(c_top, b3, M), s2);
+    EarPlanW pl;
+    make_set(pl.set[0], bot.row_q, bot.c_q, L, U);
+    make_set(pl.set[1], bot.row_p, bot.c_p, L, U);
+    make_set(pl.set[2], top.row_q, top.c_q, L, U);
+    make_set(pl.set[3], top.row_p, top.c_p, L, U);
+    // fold the blend chain into 16 weights (apply_hrtf.py:90-91, :98-99, :268-269, :276-277)
+    const double cC[2] = {1.0 - (double)f4, (double)f4};
+    double wrb[3], wbb[4], wbt[3];
+    {
+        const double s0 = (1.0 - a) * cC[0], s1 = (1.0 - a) * cC[1], g = (double)f3;
+        wrb[0] = s0 * (1.0 - g); wrb[1] = s0 * g + s1 * (1.0 - g); wrb[2] = s1 * g;
+        const double h = (double)bot.f2;
+        wbb[0] = wrb[0] * (1.0 - h); wbb[1] = wrb[0] * h + wrb[1] * (1.0 - h);
+        wbb[2] = wrb[1] * h + wrb[2] * (1.0 - h); wbb[3] = wrb[2] * h;
+        const double k = (double)bot.f1;
+        pl.w[0] = (float)(ab * wbb[0] * (1.0 - k));
+        pl.w[1] = (float)(ab * (wbb[0] * k + wbb[1] * (1.0 - k)));
+        pl.w[2] = (float)(ab * (wbb[1] * k + wbb[2] * (1.0 - k)));
+        pl.w[3] = (float)(ab * (wbb[2] * k + wbb[3] * (1.0 - k)));
+        pl.w[4] = (float)(ab * wbb[3] * k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pl.w[5 + j] = (float)((1.0 - ab) * wbb[j]);
+    }
+    {
+        const double r0 = a * cC[0], r1 = a * cC[1], h = (double)top.f2;
+        wbt[0] = r0 * (1.0 - h); wbt[1] = r0 * h + r1 * (1.0 - h); wbt[2] = r1 * h;
+        const double k = (double)top.f1;
+        pl.w[9] = (float)(at * wbt[0] * (1.0 - k));
+        pl.w[10] = (float)(at * (wbt[0] * k + wbt[1] * (1.0 - k)));
+        pl.w[11] = (float)(at * (wbt[1] * k + wbt[2] * (1.0 - k)));
+        pl.w[12] = (float)(at * wbt[2] * k);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pl.w[13 + j] = (float)((1.0 - at) * wbt[j]);
+    }
+    plans[t] = pl;
+}
+
+// eval kernel: one wave per (query, ear).  The 128-byte plan is fetched with ONE coalesced vector
+// load (lane k = word k; the scalar cache cannot stream 57 MB of plans) and spread into SGPRs with
+// v_readlane; the next row's plan is requested before the current row is evaluated.
+static_assert(sizeof(EarPlanW) == 128, "one plan = 32 words = one 128-byte load per wave");
+
+__global__ __launch_bounds__(256) void bas_interp2d_eval_kernel(const float *__restrict__ packed,
+                                                                  const EarPlanW *__restrict__ plans,
+                                                                  long n_rows, int L, int U,
+                                                                  float *__restrict__ H) {
+    const int lane = threadIdx.x & 63;
+    const long wave0 = rfl((int)(threadIdx.x >> 6)) + blockIdx.x * 4L;
+    const long n_waves = gridDim.x * 4L;
+    const int *pw = reinterpret_cast<const int *>(plans) + (lane & 31);
+    int word_next = wave0 < n_rows ? pw[wave0 * 32] : 0;
+    for (long row = wave0; row < n_rows; row += n_waves) {   // row = query * 2 + ear
+        const int word = word_next;
+        const long nrow = row + n_waves;
+        word_next = pw[(nrow < n_rows ? nrow : row) * 32];
+        int base[4], ph0[4], o[4];
+        float wt[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            base[t] = __builtin_amdgcn_readlane(word, 4 * t);
+            ph0[t] = __builtin_amdgcn_readlane(word, 4 * t + 1);
+            o[t] = __builtin_amdgcn_readlane(word, 4 * t + 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wt[k] = __int_as_float(__builtin_amdgcn_readlane(word, 16 + k));
+        float *Hq = H + row * L;
+        for (int m = 2 * lane; m < L; m += 128) {            // a lane owns taps m, m + 1
+            f32x2 acc = f32x2{0.f, 0.f};
+            acc = set_dot<5>(packed, base[0], ph0[0], o[0], wt, m, L, U, acc);
+            acc = set_dot<4>(packed, base[1], ph0[1], o[1], wt + 5, m, L, U, acc);
+            acc = set_dot<4>(packed, base[2], ph0[2], o[2], wt + 9, m, L, U, acc);
+            acc = set_dot<3>(packed, base[3], ph0[3], o[3], wt + 13, m, L, U, acc);
+            if (m + 1 < L) *reinterpret_cast<f32x2_a4 *>(Hq + m) = acc;
+            else Hq[m] = acc.x;                              // odd L: the last tap stands alone
         }
     }
 }
 
-static int pow2_shift(int U) {
-    for (int s = 0; s < 30; ++s)
-        if ((1 << s) == U) return s;
-    return -1;
+extern "C" size_t bas_interp2d_workspace_bytes(int n) {
+    return n > 0 ? (size_t)n * 2 * sizeof(EarPlanW) + 16 : 16;
 }
 
 extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *idx,
-                                const double *w, int n, int ndir, int L, int U, float *H,
-                                bas_stream_t stream) {
+                                const double *w, int n, int ndir, int L, int U, float *H, void *ws,
+                                size_t ws_bytes, bas_stream_t stream) {
     BAS_REQUIRE(packed && diffs && idx && w && H, BAS_E_NULL, "bas_interp2d_f32: null pointer");
     BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
                 "bas_interp2d_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
-    BAS_REQUIRE((long)2 * ndir * L * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_f32: table too large");
+    BAS_REQUIRE((long)2 * ndir * (L + 2) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_f32: table too large");
     if (n == 0) return 0;
-    int grid = (n + BAS_QB - 1) / BAS_QB;
-    int ush = pow2_shift(U);
-    if (ush >= 0)
-        hipLaunchKernelGGL(bas_interp2d_kernel<true>, dim3(grid), dim3(256), 0, bas_stream(stream), packed,
-                           diffs, idx, w, n, ndir, L, U, ush, H);
-    else
-        hipLaunchKernelGGL(bas_interp2d_kernel<false>, dim3(grid), dim3(256), 0, bas_stream(stream), packed,
-                           diffs, idx, w, n, ndir, L, U, 0, H);
-    return bas_check_launch("bas_interp2d_f32");
+    BAS_REQUIRE(ws && ws_bytes >= bas_interp2d_workspace_bytes(n) && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
+                BAS_E_WORKSPACE, "bas_interp2d_f32: 16-byte aligned workspace of %zu bytes needed, %zu given",
+                bas_interp2d_workspace_bytes(n), ws_bytes);
+    EarPlanW *plans = reinterpret_cast<EarPlanW *>(ws);
+    hipStream_t st = bas_stream(stream);
+    const long rows = 2L * n;
+    hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
+                       w, n, ndir, L, U, plans);
+    int rc = bas_check_launch("bas_interp2d_f32(plan)");
+    if (rc) return rc;
+    long blocks = (rows + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(bas_interp2d_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, plans, rows, L, U,
+                       H);
+    return bas_check_launch("bas_interp2d_f32(eval)");
 }
 
 // ---------------------------------------------------------------------------
@@ -260,7 +378,7 @@ __global__ __launch_bounds__(256) void bas_ring_kernel(const float *__restrict__
         int p = clamp_dir(pq[2 * q], ndir), r = clamp_dir(pq[2 * q + 1], ndir);
         RingPlan rp;
         double s2;
-        ring_plan(rp, diffs + (long)e * ndir * ndir, e, ndir, p, r, alpha[q], L, U, (long long)j * step, s2);
+        ring_plan(rp, diffs + (long)e * ndir * ndir, e, ndir, p, r, alpha[q], L, U, j * step, s2);
         // generic-position reads (the lane's own position is folded into c): m = 0
         float res[1];
         ring_eval<false, 1>(packed, rp, 0, L, U, 0, M, res);
@@ -276,7 +394,7 @@ extern "C" int bas_ring_interp_f32(const float *packed, const double *diffs, con
     BAS_REQUIRE(packed && diffs && pq && alpha && out, BAS_E_NULL, "bas_ring_interp_f32: null pointer");
     BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
                 "bas_ring_interp_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
-    BAS_REQUIRE((long)2 * ndir * L * U < (1L << 31), BAS_E_SHAPE, "bas_ring_interp_f32: table too large");
+    BAS_REQUIRE((long)2 * ndir * (L + 2) * U < (1L << 31), BAS_E_SHAPE, "bas_ring_interp_f32: table too large");
     if (n == 0) return 0;
     int step = return_upsampled ? 1 : U;
     int Mout = return_upsampled ? L * U : L;

@@ -398,9 +398,10 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
 // 8 + 63 LDS words of 128 bit.  LDS holds only the x window and, per chunk slot, the pair
 // (H_c, H_{c+1} - H_c) interleaved per tap as (h0_L, h0_R, d_L, d_R); the lane forms
 // g = h0 + al d (al = its row's crossfade weight) with one packed FMA per tap, 6 % on top of the FIR.
-// Nothing row-specific is staged, so a pass costs two barriers and a few dozen LDS stores, and with
-// ~38 KB of LDS four 2-wave workgroups share a CU.  Needs S a power of two (>= 32) and at most 12 chunk slots per tile (K >= 416).
-#define HD_NW 2                               // waves per workgroup
+// Nothing row-specific is staged, so a pass costs two barriers and a few dozen LDS stores; with ~71 KB
+// of LDS two 4-wave workgroups share a CU.  Needs S a power of two (>= 32) and at most 20 chunk
+// slots per tile (K >= 448).
+#define HD_NW 4                               // waves per workgroup: one per SIMD, so the CU stays balanced
 #define HD_THREADS (64 * HD_NW)
 #define HD_TILE (2048 * HD_NW)                // outputs per tile
 #define HD_HALO (RT_SEG / 32)                 // input rows above a tile (4)
@@ -408,7 +409,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
 #define HD_XR (HD_ROWS + 1)                   // odd: conflict-free column-major image
 #define HD_NX ((HD_ROWS * 8 + HD_THREADS - 1) / HD_THREADS)     // float4 of x per thread (9)
 #define HD_SLOT (RT_SEG * 4 + 4)              // floats per chunk slot (+16 B: slots on distinct banks)
-#define HD_MAXSLOTS 12
+#define HD_MAXSLOTS 20
+#define HD_HALFSLOTS (HD_MAXSLOTS / 2)     // chunk slots staged by one half of the threads
 #define HD_X_FLOATS (8 * HD_XR * 4)
 
 __device__ __forceinline__ void hd_load_xrow(float (&xr)[32], const f32x4 *__restrict__ xrow) {
@@ -496,6 +498,10 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
     const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
     const long n_pass = (unit1 - unit0) * nseg;
     if (n_pass <= 0) return;
+#ifdef BAS_STAMPS
+    const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st_fir = 0;
+#endif
 
     f32x2 acc[32];
 #pragma unroll
@@ -546,15 +552,20 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             m = m < 0 ? 0 : (m > A.T_in - 4 ? A.T_in - 4 : m);
             xv[j] = *reinterpret_cast<const f32x4 *>(xsrc + m);
         }
-        float hl[HD_MAXSLOTS + 1], hr[HD_MAXSLOTS + 1];
+        // chunk IRs: thread = (tap, half); each half of the threads stages half of the chunk slots
+        const int tap = tid & (RT_SEG - 1);
+        const int slot_a = (tid >> 7) * ((nslots + 1) >> 1);
+        int slot_b = slot_a + ((nslots + 1) >> 1);
+        if (slot_b > nslots) slot_b = nslots;
+        float hl[HD_HALFSLOTS + 1], hr[HD_HALFSLOTS + 1];
         {
-            int k = seg0 + tid;
+            int k = seg0 + tap;
             if (k > A.L - 1) k = A.L - 1;
             const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
 #pragma unroll
-            for (int j = 0; j <= HD_MAXSLOTS; ++j) {
-                if (j <= nslots) {                           // uniform
-                    const float *p = Hk + (long)clampi(c0 + j, 0, A.n_chunks) * 2 * A.L;
+            for (int j = 0; j <= HD_HALFSLOTS; ++j) {
+                if (slot_a + j <= slot_b) {                  // uniform per wave
+                    const float *p = Hk + (long)clampi(c0 + slot_a + j, 0, A.n_chunks) * 2 * A.L;
                     hl[j] = p[0];
                     hr[j] = p[A.L];
                 }
@@ -570,12 +581,12 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             v = (m >= 0 && m < A.T_in) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             if (i4 < nrows * 8) xs4[(i4 & 7) * HD_XR + (i4 >> 3)] = v;
         }
-        if (tid < Lseg) {
-            const float live = seg0 + tid < A.L ? 1.0f : 0.0f;   // taps >= L read as zero
-            f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + tid;
+        if (tap < Lseg) {
+            const float live = seg0 + tap < A.L ? 1.0f : 0.0f;   // taps >= L read as zero
+            f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tap;
 #pragma unroll
-            for (int j = 0; j < HD_MAXSLOTS; ++j) {
-                if (j < nslots)
+            for (int j = 0; j < HD_HALFSLOTS; ++j) {
+                if (slot_a + j < slot_b)
                     dst[j * (HD_SLOT / 4)] = f32x4{hl[j], hr[j], hl[j + 1] - hl[j], hr[j + 1] - hr[j]} * live;
             }
         }
@@ -609,6 +620,7 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                 sl -= 1;
             }
         };
+        STAMP(tf0);
         for (int rp = 0; rp <= halo; ++rp) {
             float al;
             const float *hdrow;
@@ -616,8 +628,22 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             hd_row_step_masked(acc, xrow, hdrow, al, mask_of(rp));
             step_done();
         }
+        STAMP(tf1);
+#ifdef BAS_STAMPS
+        st_fir += tf1 - tf0;
+#endif
     }
     flush(cur_tile);
+#ifdef BAS_STAMPS
+    if (lane == 0 && blockIdx.x < 1024) {
+        unsigned long long *d = bas_dbg_stamps + (blockIdx.x * 4 + wv) * 8;
+        d[0] = st_begin;
+        d[1] = __builtin_amdgcn_s_memrealtime();
+        d[2] = st_fir;
+        d[3] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        d[4] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // HW_REG_XCC_ID
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------
@@ -793,7 +819,7 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
         p.hd_slots = hd_slots;
         p.lds_bytes = (size_t)(HD_X_FLOATS + hd_slots * HD_SLOT) * sizeof(float);
         wg_per_cu = (long)(160 * 1024 / p.lds_bytes);
-        if (wg_per_cu > 4) wg_per_cu = 4;
+        if (wg_per_cu > 2) wg_per_cu = 2;
         if (wg_per_cu < 1) wg_per_cu = 1;
     } else {
         p.tile = RT_TILE;

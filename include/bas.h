@@ -50,10 +50,14 @@ const char *bas_last_error(void);
  * (apply_hrtf.py:23-46): irs_left/irs_right truncated to M = samples_to_keep*U
  * columns (:43-44).  Re-lays the row-major table
  *     irs   [2 ears][ndir][M]            (ear 0 = left)
- * as phase planes
- *     packed[2 ears][ndir][U][L],  packed[e][p][i % U][i / U] = irs[e][p][i],
- * L = M / U, so that the stride-U reads of a fractional shift followed by
- * decimation (apply_hrtf.py:156-165) are contiguous across lanes. */
+ * as phase planes with a guard float at either end of every plane
+ *     packed[2 ears][ndir][U][L + 2],  packed[e][p][i % U][1 + i / U] = irs[e][p][i],
+ *     packed[e][p][ph][0] = packed[e][p][ph][L],  packed[e][p][ph][L + 1] = packed[e][p][ph][1]
+ * (circular neighbours), L = M / U, so that the stride-U reads of a fractional
+ * shift followed by decimation (apply_hrtf.py:156-165) are contiguous across
+ * lanes and neither "one sample earlier" nor "the next tap" needs a wrap test.  bas_table_packed_floats() gives
+ * the size of `packed` in floats (0 for invalid shapes). */
+size_t bas_table_packed_floats(int ndir, int M, int U);
 int bas_table_pack_f32(const float *irs, int ndir, int M, int U, float *packed,
                        bas_stream_t stream);
 
@@ -83,10 +87,13 @@ int bas_ring_interp_f32(const float *packed, const double *diffs, const int32_t 
  * all table arithmetic (:219-279).
  *   idx [n][4] int32 = (top_before, top_after, bot_before, bot_after)
  *   w   [n][3] f64   = (top_alpha, bot_alpha, a)
- *   H   [n][2 ears][L] f32                                        */
+ *   H   [n][2 ears][L] f32
+ *   ws / ws_bytes: 16-byte aligned scratch of bas_interp2d_workspace_bytes(n) bytes
+ *      (per-(query, ear) read plans handed from the plan kernel to the eval kernel). */
+size_t bas_interp2d_workspace_bytes(int n);
 int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *idx,
-                     const double *w, int n, int ndir, int L, int U, float *H,
-                     bas_stream_t stream);
+                     const double *w, int n, int ndir, int L, int U, float *H, void *ws,
+                     size_t ws_bytes, bas_stream_t stream);
 
 /* ---- a7/a8: make_signal_move_2d inner loops (apply_hrtf.py:431-453) ---------
  * For every source s, input sample m and tap k:

@@ -77,7 +77,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == -2 and b"multiple of K" in lib.bas_last_error()
     rc = lib.bas_render_mix_f32(None, 1024, None, 1, 1024, 512, 32, 128, None, 0, None, None, 0, None)
     assert rc == -1
-    rc = lib.bas_interp2d_f32(None, None, None, None, 1, 187, 128, 8, None, None)
+    rc = lib.bas_interp2d_f32(None, None, None, None, 1, 187, 128, 8, None, None, 0, None)
     assert rc == -1
     rc = lib.bas_table_pack_f32(p, 187, 1001, 8, p, None)
     assert rc == -2
