@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--subchunk", type=int, default=32)
     ap.add_argument("--taps", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sources-per-core", type=int, default=2)
+    ap.add_argument("--cpu-sources-per-core", type=int, default=16)
     return ap.parse_args()
 
 
@@ -98,7 +98,7 @@ def host_cores():
 def cpu_baseline(args, n, t_out):
     import multiprocessing as mp
     cores = host_cores()
-    per = args.cpu_sources_per_core
+    per = max(1, min(args.cpu_sources_per_core, -(-args.sources // cores)))   # at most the whole scene
     jobs = [(c * per, per, n, args.chunk, args.subchunk, args.taps, args.sources) for c in range(cores)]
     ctx = mp.get_context("spawn")
     t0 = time.perf_counter()
@@ -251,7 +251,7 @@ def main():
             "source_samples_per_s": world * n_src * in_length * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": algo_bytes / fir_avg_s / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / fir_avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "bas_render_rows32_kernel", "kernel_ms": fir_avg_s * 1e3,
+                         "kernel": _hip.lib().bas_render_kernel_name(n_src, in_length, k, s, l).decode(), "kernel_ms": fir_avg_s * 1e3,
                          "algorithmic_bytes": algo_bytes},
             "valu": {"achieved": algo_flops / fir_avg_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": algo_flops / fir_avg_s / 1e12 / FP32_VALU_PEAK_TF,

@@ -25,6 +25,7 @@ SIGNATURES = {
     "bas_interp2d_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "bas_render_workspace_bytes": (_c_size_t, [_c_int, _c_long, _c_int, _c_int, _c_int]),
+    "bas_render_kernel_name": (ctypes.c_char_p, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_mix_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_long, _c_int, _c_int, _c_int,
                                     _c_void_p, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
     "bas_render_mix_profiled_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_long, _c_int, _c_int,

@@ -862,6 +862,13 @@ extern "C" size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S,
     return need + 16;
 }
 
+extern "C" const char *bas_render_kernel_name(int n_src, long T_in, int K, int S, int L) {
+    if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return "bas_render_generic_kernel";
+    RenderPlan p = plan_render(n_src, T_in, K, S, L, true);
+    return p.kind == KIND_HD ? "bas_render_hd_kernel"
+                             : (p.kind == KIND_ROWS32 ? "bas_render_rows32_kernel" : "bas_render_generic_kernel");
+}
+
 static int render_mix_impl(const float *x, long x_stride, const float *H, int n_src, long T_in, int K, int S,
                            int L, float *y, int accumulate, float *peak, void *ws, size_t ws_bytes,
                            bas_stream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {

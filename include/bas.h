@@ -111,6 +111,11 @@ int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *id
  *   ws / ws_bytes: scratch of at least bas_render_workspace_bytes(...) bytes. */
 size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S, int L);
 
+/* Name of the FIR kernel bas_render_mix_f32 launches for these sizes with aligned
+ * operands ("bas_render_hd_kernel", "bas_render_rows32_kernel" or
+ * "bas_render_generic_kernel"); for profiling tools. */
+const char *bas_render_kernel_name(int n_src, long T_in, int K, int S, int L);
+
 int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,
                        int K, int S, int L, float *y, int accumulate, float *peak,
                        void *ws, size_t ws_bytes, bas_stream_t stream);
