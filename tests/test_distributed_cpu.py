@@ -1,0 +1,108 @@
+"""World-size-2 gloo test (CPU) of the multi-GPU path: source sharding + ONE gather of the
+partial stereo mixes + fixed-order sum + peak rule on the root.  The HIP renderer cannot run
+without a GPU, so the product functions are driven with injected CPU stand-ins (the oracle as
+the per-rank renderer, numpy as the mixer); what is under test is
+binaural-audio-synthesis_amd/distributed.py: the shard arithmetic, the collective and its
+ordering, and that only the root returns a result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import binaural_audio_synthesis_amd as bas
+from oracle import bas_oracle as orc
+
+N_SRC, N, K, S, L = 5, 3000, 512, 32, 128
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _scene():
+    host = bas.synth.make_table("consistent", 0).truncated(L)
+    sigs = np.stack([bas.synth.integer_noise(50 + i, N, 0.6) for i in range(N_SRC)])   # loud: peak rule fires
+    in_length, _ = orc.render_lengths(N, K, L)
+    t = np.arange(0, in_length + 1, K, dtype=np.float64)
+    elev = np.empty((N_SRC, t.size))
+    azim = np.empty((N_SRC, t.size))
+    for i in range(N_SRC):
+        tr = bas.synth.trajectory(("spiral", "circle_askew")[i % 2], period_s=0.05 + 0.02 * i,
+                                  length_s=N / 44100, turns=2.0, phase=i)
+        elev[i], azim[i] = tr(t)
+    return host, sigs, elev, azim
+
+
+def _cpu_render(host):
+    def render(signals, k, s, elev, azim, tbl):
+        irs = [np.stack([orc.interp2d(host, elev[i, c], azim[i, c]) for c in range(elev.shape[1])])
+               for i in range(signals.shape[0])]
+        if not irs:
+            in_length, out_length = orc.render_lengths(N, k, L)
+            return torch.zeros((out_length, 2), dtype=torch.float32)
+        return torch.from_numpy(orc.render_mix(signals, k, s, irs, normalize=False).copy())
+    return render
+
+
+def _cpu_mix(parts):
+    acc = parts[0].clone()
+    for p in range(1, parts.shape[0]):
+        acc += parts[p]                                  # fixed order, like bas_mix_partials_f32
+    return acc, acc.abs().max().reshape(1)
+
+
+def _cpu_scale(y, peak):
+    return y / peak if float(peak) > 1 else y
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host, sigs, elev, azim = _scene()
+    mine = bas.distributed.shard_sources(N_SRC, world, rank)
+    sl = slice(mine.start, mine.stop)
+    y = bas.distributed.render_sources_sharded(sigs[sl], K, S, elev[sl], azim[sl], None, render_fn=_cpu_render(host),
+                                               mix_fn=_cpu_mix, scale_fn=_cpu_scale)
+    if rank == 0:
+        assert y is not None
+        np.save(out_path, y.numpy())
+    else:
+        assert y is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_sources_partition():
+    for n, w in ((256, 8), (5, 2), (3, 4), (0, 2), (1024, 8)):
+        got = [i for r in range(w) for i in bas.distributed.shard_sources(n, w, r)]
+        assert got == list(range(n))
+        sizes = [len(bas.distributed.shard_sources(n, w, r)) for r in range(w)]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_gather_matches_single_process(tmp_path):
+    out = str(tmp_path / "y.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    host, sigs, elev, azim = _scene()
+    irs = [np.stack([orc.interp2d(host, elev[i, c], azim[i, c]) for c in range(elev.shape[1])]) for i in range(N_SRC)]
+    want = orc.render_mix(sigs, K, S, irs)               # whole scene in one process, peak rule on the mix
+    assert got.shape == want.shape
+    assert np.abs(want).max() == pytest.approx(1.0)      # the peak rule fired on the mix
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-6
+
+
+def test_single_process_gather_is_identity():
+    host, sigs, elev, azim = _scene()
+    y = bas.distributed.render_sources_sharded(sigs, K, S, elev, azim, None, render_fn=_cpu_render(host),
+                                               mix_fn=_cpu_mix, scale_fn=_cpu_scale, normalize="none")
+    irs = [np.stack([orc.interp2d(host, elev[i, c], azim[i, c]) for c in range(elev.shape[1])]) for i in range(N_SRC)]
+    want = orc.render_mix(sigs, K, S, irs, normalize=False)
+    assert np.array_equal(y.numpy(), want)

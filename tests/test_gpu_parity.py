@@ -164,6 +164,38 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
     assert rel_err(got, want) <= REL, rel_err(got, want)
 
 
+@pytest.mark.parametrize("force,n_src,n,k,s,l", [("rows32", 4, 9000, 512, 32, 128),   # forced fallback kernel
+                                                   ("rows32", 3, 6000, 512, 64, 100),
+                                                   ("generic", 2, 3000, 512, 32, 128),
+                                                   ("", 3, 5000, 128, 32, 128),          # K < 448: rows32 by itself
+                                                   ("", 3, 5000, 1024, 256, 128),        # hd kernel, S > 32
+                                                   ("", 2, 4000, 512, 32, 99)])          # odd L
+def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_src, n, k, s, l):
+    """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL."""
+    if force:
+        monkeypatch.setenv("BAS_FORCE_KERNEL", force)
+    name = bas._hip.lib().bas_render_kernel_name(n_src, -(-n // k) * k, k, s, l).decode()
+    if force:
+        assert force in name
+    if (l, "consistent") == (99, "consistent"):
+        h = tables["consistent"].truncated(99)
+        d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    else:
+        h, d = dev_tables[("consistent", l)]
+    sigs, elev, azim, irs = _mix_case(h, n_src, n, k, s, seed=700)
+    want = orc.render_mix(sigs, k, s, irs)
+    got = bas.render_sources(sigs, k, s, elev, azim, d).cpu().numpy()
+    assert rel_err(got, want) <= REL, (name, rel_err(got, want))
+
+
+def test_kernel_selection():
+    lib = bas._hip.lib()
+    assert lib.bas_render_kernel_name(256, 441344, 512, 32, 128) == b"bas_render_hd_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 128, 32, 128) == b"bas_render_rows32_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 128, 16, 128) == b"bas_render_generic_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 480, 96, 128) == b"bas_render_rows32_kernel"   # S not a power of two
+
+
 def test_long_ir_segments(tables):
     """L = 300 > 128 exercises the 128-tap segment loop of the fast kernel."""
     h = tables["consistent"].truncated(300)
