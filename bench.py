@@ -8,8 +8,9 @@ Workload (config 4 of BASELINE.json, per GPU): 256 concurrent moving sources x 1
 44.1 kHz mono, chunk K=512, subchunk S=32, IR L=128 taps (samples_to_keep=128, U=8),
 synthetic table + seeded noise + per-source spiral/circle trajectories,
 mixed to one stereo pair.  One "step" = one full pass of the hot path over that batch
-with inputs resident in HBM: bas_interp2d_f32 (all chunk IRs) -> bas_render_mix_f32
-(time-varying FIR + overlap-add + mix + fused peak) -> [N>1: one RCCL gather of the
+with inputs resident in HBM: bas_interp2d_plan_f32 (read plans of all chunk IRs) -> bas_render_mix_fused_f32
+(chunk IRs evaluated from the table inside the FIR kernel; time-varying FIR + overlap-add + mix +
+fused peak) -> [N>1: one RCCL gather of the
 partial mixes to rank 0 + fixed-order sum] -> peak rule.
 
 Scaling is WEAK: every GPU renders its own 256 sources (the scene has 256*N sources)
@@ -146,10 +147,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    # rehearsal knobs (a 1-GPU box): BAS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0,
+    # BAS_BENCH_BACKEND=gloo stages the gather through host memory.  The driver's runs use neither.
+    if os.environ.get("BAS_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("BAS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n = int(round(args.seconds * FS))
     k, s, l, n_src = args.chunk, args.subchunk, args.taps, args.sources
@@ -173,7 +182,6 @@ def main():
     idx_h, w_h = bas.sphere.interpolation_params_batch(elev, azim)
     idx = torch.from_numpy(idx_h.reshape(-1, 4)).to(dev)
     w = torch.from_numpy(w_h.reshape(-1, 3)).to(dev)
-    H = torch.empty((n_src * n_q, 2, l), dtype=torch.float32, device=dev)
     y = torch.empty((2, t_out), dtype=torch.float32, device=dev)
     ws = torch.empty((_hip.lib().bas_render_workspace_bytes(n_src, in_length, k, s, l),), dtype=torch.uint8,
                      device=dev)
@@ -183,20 +191,28 @@ def main():
     peak = torch.empty((1,), dtype=torch.float32, device=dev)
     ev = HipEvents(args.steps)
 
+    fused = None if os.environ.get("BAS_BENCH_FUSED", "1") == "1" else False
+
     def step(i_event=None):
-        bas.interpolate_2d_params(tbl, idx, w, out=H, validate=False, ws=ws_i)
         events = None if i_event is None else ev.pairs[i_event]
-        _, pk = bas.apply_hrtf.render_device(x, k, s, H.view(n_src, n_q, 2, l), l, normalize="none", out=y,
-                                             events=events, ws=ws)
+        _, pk = bas.apply_hrtf.render_params_device(x, k, s, tbl, idx, w, normalize="none", out=y, events=events,
+                                                    ws=ws, ws_plans=ws_i, fused=fused)
         stream = _hip.current_stream(dev)
+        if world > 1 and backend != "nccl":              # rehearsal only: gather through host memory
+            y_host = y.cpu()
+            if rank == 0:
+                host_parts = [torch.empty_like(y_host) for _ in range(world)]
+                dist.gather(y_host, gather_list=host_parts, dst=0)
+                parts.copy_(torch.stack(host_parts))
+            else:
+                dist.gather(y_host, gather_list=None, dst=0)
+        elif world > 1:
+            dist.gather(y, gather_list=list(parts.unbind(0)) if rank == 0 else None, dst=0)
         if world > 1:
             if rank == 0:
-                dist.gather(y, gather_list=list(parts.unbind(0)), dst=0)
                 _hip.call("bas_mix_partials_f32", _hip.ptr(parts), world, 2 * t_out, 2 * t_out, _hip.ptr(y_final),
                           _hip.ptr(peak), stream)
                 _hip.call("bas_scale_by_peak_f32", _hip.ptr(y_final), 2 * t_out, _hip.ptr(peak), stream)
-            else:
-                dist.gather(y, gather_list=None, dst=0)
         else:
             _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(pk), stream)
 

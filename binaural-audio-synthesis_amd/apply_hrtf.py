@@ -205,7 +205,58 @@ def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=Non
     return y, peak
 
 
-def render_sources(signals, chunksize, subchunksize, elev, azim, tbl, normalize="mix"):
+def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix", out=None, events=None,
+                         ws=None, ws_plans=None, fused=None):
+    """interpolate_2d + render for precomputed parameters: x [n_src, T_in] device float32,
+    idx int32 [n_src*(n_chunks+1), 4], w float64 [.., 3] on the device.  Uses the fused kernel
+    (chunk IRs evaluated inside the FIR kernel, never stored) when the sizes allow it, else
+    bas_interp2d_f32 + bas_render_mix_f32.  Returns (y [2, T_out], peak)."""
+    import torch
+    tbl = as_device_table(tbl)
+    dev = x.device
+    n_src, t_in = x.shape
+    lib = _hip.lib()
+    if fused is None:
+        fused = bool(lib.bas_render_fused_supported(n_src, t_in, chunksize, subchunksize, tbl.L)) and \
+            x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
+    n_q = idx.shape[0]
+    if not fused:
+        H = interpolate_2d_params(tbl, idx, w, validate=False, ws=ws_plans)
+        return render_device(x, chunksize, subchunksize, H.view(n_src, n_q // max(n_src, 1), 2, tbl.L), tbl.L,
+                             normalize, out=out, events=events, ws=ws)
+    t_out = t_in + tbl.L - 1
+    y = out if out is not None else torch.empty((2, t_out), dtype=torch.float32, device=dev)
+    peak = torch.empty((1,), dtype=torch.float32, device=dev)
+    pb = lib.bas_interp2d_workspace_bytes(n_q)
+    if ws_plans is None or ws_plans.numel() < pb:
+        ws_plans = torch.empty((pb,), dtype=torch.uint8, device=dev)
+    wb = lib.bas_render_workspace_bytes(n_src, t_in, chunksize, subchunksize, tbl.L)
+    if ws is None or ws.numel() < wb:
+        ws = torch.empty((wb,), dtype=torch.uint8, device=dev)
+    stream = _hip.current_stream(dev)
+    _hip.call("bas_interp2d_plan_f32", _hip.ptr(tbl.diffs), _hip.ptr(idx), _hip.ptr(w), n_q, tbl.ndir, tbl.L,
+              tbl.upsampling, _hip.ptr(ws_plans), ws_plans.numel(), stream)
+    ev = events if events is not None else (None, None)
+    _hip.call("bas_render_mix_fused_f32", _hip.ptr(x), x.stride(0), _hip.ptr(tbl.packed), _hip.ptr(ws_plans), n_src,
+              t_in, chunksize, subchunksize, tbl.L, tbl.upsampling, _hip.ptr(y), 0, _hip.ptr(peak), _hip.ptr(ws),
+              ws.numel(), stream, ev[0], ev[1])
+    if normalize == "mix":
+        _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(peak), stream)
+    elif normalize != "none":
+        raise ValueError("normalize must be 'mix' or 'none'")
+    return y, peak
+
+
+def _params_to_device(tbl, idx, w):
+    import torch
+    idx_t = torch.as_tensor(idx, dtype=torch.int32).reshape(-1, 4).contiguous().to(tbl.device)
+    w_t = torch.as_tensor(w, dtype=torch.float64).reshape(-1, 3).contiguous().to(tbl.device)
+    if idx_t.shape[0] and (int(idx_t.min()) < 0 or int(idx_t.max()) >= tbl.ndir):
+        raise IndexError("HRTF database index out of range")
+    return idx_t, w_t
+
+
+def render_sources(signals, chunksize, subchunksize, elev, azim, tbl, normalize="mix", fused=None):
     """Render and mix many independently moving sources.
 
     signals: [n_src, N] (numpy or tensor); elev/azim: float64 [n_src, n_chunks+1]
@@ -229,8 +280,8 @@ def render_sources(signals, chunksize, subchunksize, elev, azim, tbl, normalize=
     idx, w = sphere.interpolation_params_batch(elev, azim)
     if idx.shape[:-1] != (n_src, n_q):
         raise ValueError(f"elev/azim must have shape ({n_src}, {n_q})")
-    H = interpolate_2d_params(tbl, idx.reshape(-1, 4), w.reshape(-1, 3)).reshape(n_src, n_q, 2, tbl.L)
-    y, _ = render_device(x, chunksize, subchunksize, H, tbl.L, normalize)
+    idx_t, w_t = _params_to_device(tbl, idx, w)
+    y, _ = render_params_device(x, chunksize, subchunksize, tbl, idx_t, w_t, normalize, fused=fused)
     return y.t()
 
 
@@ -265,8 +316,8 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     x = torch.zeros((1, in_length), dtype=torch.float32, device=dev)         # :405-406
     src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
     x[0, :n] = src.to(device=dev, dtype=torch.float32)
-    H = interpolate_2d_params(tbl, idx, w).reshape(1, len(times), 2, tbl.L)
-    y, _ = render_device(x, int(chunksize), int(subchunksize), H, tbl.L, "mix")
+    idx_t, w_t = _params_to_device(tbl, idx, w)
+    y, _ = render_params_device(x, int(chunksize), int(subchunksize), tbl, idx_t, w_t, "mix")
     if verbose:
         print(' 100.0%      ')
     out = y.t()                                                              # (out_length, 2), F-ordered like :459

@@ -180,49 +180,7 @@ __device__ __forceinline__ void ring_plan(RingPlan &rp, const double *__restrict
 // 16 loads off scalar bases and 16 FMAs with scalar weights.
 #define BAS_QB 16      // queries per workgroup
 
-struct SetPlan {
-    int base;          // float index of plane ph0's sample 0 in `packed` (guard is at base - 1)
-    int ph0;           // phase of read j = 0; reads j <= ph0 stay in plane ph0 - j at offset o,
-    int o;             // reads j > ph0 continue in plane ph0 - j + U one sample earlier
-    int pad;
-};
-
-struct EarPlanW {
-    SetPlan set[4];
-    float w[16];       // same order as the sets: 5 + 4 + 4 + 3
-};
-
-__device__ __forceinline__ void make_set(SetPlan &sp, int row, int c, int L, int U) {
-    const int o = c / U, ph = c - o * U;           // c in [0, M)
-    sp.base = row + ph * (L + 2) + 1;
-    sp.ph0 = ph;
-    sp.o = o;
-    sp.pad = 0;
-}
-
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ float rflf(float v) {
-    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-}
-
-typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
-
-// acc += sum_j w[j] * packed[plane(j)][wrap(m + o) (- 1 after the phase wrapped) + {0, 1}]
-template <int N>
-__device__ __forceinline__ f32x2 set_dot(const float *__restrict__ packed, int base, int ph0, int o,
-                                          const float *w, int m, int L, int U, f32x2 acc) {
-    const unsigned idx = (unsigned)(m + o);                  // m < L, o < L
-    const unsigned wr = idx - (unsigned)L;
-    const unsigned off = idx < wr ? idx : wr;                // idx >= L ? idx - L : idx
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        // wave-uniform plane base; j > ph0: plane + U, one sample earlier (the guards make -1 and +1 safe)
-        const int pb = j <= ph0 ? base - j * (L + 2) : base + (U - j) * (L + 2) - 1;
-        const f32x2 v = *reinterpret_cast<const f32x2_a4 *>(packed + pb + off);
-        acc = __builtin_elementwise_fma(v, f32x2{w[j], w[j]}, acc);
-    }
-    return acc;
-}
+#include "bas_plan.h"
 
 // plan kernel: one thread per (query, ear)
 __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__restrict__ diffs,
@@ -307,23 +265,9 @@ __global__ __launch_bounds__(256) void bas_interp2d_eval_kernel(const float *__r
         const int word = word_next;
         const long nrow = row + n_waves;
         word_next = pw[(nrow < n_rows ? nrow : row) * 32];
-        int base[4], ph0[4], o[4];
-        float wt[16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            base[t] = __builtin_amdgcn_readlane(word, 4 * t);
-            ph0[t] = __builtin_amdgcn_readlane(word, 4 * t + 1);
-            o[t] = __builtin_amdgcn_readlane(word, 4 * t + 2);
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wt[k] = __int_as_float(__builtin_amdgcn_readlane(word, 16 + k));
         float *Hq = H + row * L;
         for (int m = 2 * lane; m < L; m += 128) {            // a lane owns taps m, m + 1
-            f32x2 acc = f32x2{0.f, 0.f};
-            acc = set_dot<5>(packed, base[0], ph0[0], o[0], wt, m, L, U, acc);
-            acc = set_dot<4>(packed, base[1], ph0[1], o[1], wt + 5, m, L, U, acc);
-            acc = set_dot<4>(packed, base[2], ph0[2], o[2], wt + 9, m, L, U, acc);
-            acc = set_dot<3>(packed, base[3], ph0[3], o[3], wt + 13, m, L, U, acc);
+            const f32x2 acc = plan_eval_pair(packed, word, m, L, U);
             if (m + 1 < L) *reinterpret_cast<f32x2_a4 *>(Hq + m) = acc;
             else Hq[m] = acc.x;                              // odd L: the last tap stands alone
         }
@@ -332,6 +276,23 @@ __global__ __launch_bounds__(256) void bas_interp2d_eval_kernel(const float *__r
 
 extern "C" size_t bas_interp2d_workspace_bytes(int n) {
     return n > 0 ? (size_t)n * 2 * sizeof(EarPlanW) + 16 : 16;
+}
+
+extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double *w, int n, int ndir,
+                                     int L, int U, void *plans, size_t plans_bytes, bas_stream_t stream) {
+    BAS_REQUIRE(diffs && idx && w, BAS_E_NULL, "bas_interp2d_plan_f32: null pointer");
+    BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
+                "bas_interp2d_plan_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
+    BAS_REQUIRE((long)2 * ndir * (L + 2) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_plan_f32: table too large");
+    if (n == 0) return 0;
+    BAS_REQUIRE(plans && plans_bytes >= bas_interp2d_workspace_bytes(n) &&
+                    reinterpret_cast<uintptr_t>(plans) % 16 == 0,
+                BAS_E_WORKSPACE, "bas_interp2d_plan_f32: 16-byte aligned buffer of %zu bytes needed, %zu given",
+                bas_interp2d_workspace_bytes(n), plans_bytes);
+    const long rows = 2L * n;
+    hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       bas_stream(stream), diffs, idx, w, n, ndir, L, U, reinterpret_cast<EarPlanW *>(plans));
+    return bas_check_launch("bas_interp2d_plan_f32");
 }
 
 extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *idx,

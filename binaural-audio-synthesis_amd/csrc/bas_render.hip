@@ -24,6 +24,7 @@
 // footprint (68 IR rows + x window = 79.4 KB) is independent of L and two
 // workgroups share a CU.  No MFMA: this is a 1-D FIR (BASELINE.json north_star).
 #include "bas_internal.h"
+#include "bas_plan.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -48,6 +49,10 @@ struct RenderArgs {
     int parts_per_wg;
     float *slab;           // [n_wg][parts_per_wg][2][RT_TILE]
     int dbg;               // ablation flags (BAS_DEBUG_FLAGS, diagnostics only)
+    // fused path (chunk IRs evaluated from read plans inside the FIR kernel, H unused)
+    const float *packed;   // table in phase-plane layout
+    const int *plans;      // [n_src][n_chunks+1][2 ears][32 words]
+    int U;
 };
 
 #ifdef BAS_STAMPS
@@ -483,6 +488,7 @@ __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4
 #undef HD_MASKED_OCTET
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs A, int nslots) {
     extern __shared__ f32x4 lds4[];
     f32x4 *xs4 = lds4;                                       // [8][HD_XR] float4
@@ -552,13 +558,26 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             m = m < 0 ? 0 : (m > A.T_in - 4 ? A.T_in - 4 : m);
             xv[j] = *reinterpret_cast<const f32x4 *>(xsrc + m);
         }
-        // chunk IRs: thread = (tap, half); each half of the threads stages half of the chunk slots
+        // chunk IRs.  Unfused: thread = (tap, half), each half of the threads stages half of the chunk
+        // slots from H.  Fused: wave wv evaluates rows (slot, ear) = wv, wv+4, .. of the nslots+1 chunk
+        // IRs straight from the table through their read plans (one 128-byte plan per row, fetched now).
         const int tap = tid & (RT_SEG - 1);
         const int slot_a = (tid >> 7) * ((nslots + 1) >> 1);
         int slot_b = slot_a + ((nslots + 1) >> 1);
         if (slot_b > nslots) slot_b = nslots;
         float hl[HD_HALFSLOTS + 1], hr[HD_HALFSLOTS + 1];
-        {
+        constexpr int HD_MAXEVAL = ((HD_MAXSLOTS + 1) * 2 + HD_NW - 1) / HD_NW;     // rows per wave
+        int pword[HD_MAXEVAL];
+        const int n_hrows = 2 * (nslots + 1);                // rows (slot, ear) of chunk IRs this pass needs
+        if (FUSED) {
+            const int *pl = A.plans + ((long)s * (A.n_chunks + 1)) * 64 + (lane & 31);
+#pragma unroll
+            for (int i = 0; i < HD_MAXEVAL; ++i) {
+                int r = wv + HD_NW * i;                      // row = slot * 2 + ear
+                if (r > n_hrows - 1) r = n_hrows - 1;        // clamped: no branch around the load
+                pword[i] = pl[(long)(clampi(c0 + (r >> 1), 0, A.n_chunks) * 2 + (r & 1)) * 32];
+            }
+        } else {
             int k = seg0 + tap;
             if (k > A.L - 1) k = A.L - 1;
             const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
@@ -581,7 +600,52 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             v = (m >= 0 && m < A.T_in) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             if (i4 < nrows * 8) xs4[(i4 & 7) * HD_XR + (i4 >> 3)] = v;
         }
-        if (tap < Lseg) {
+        if (FUSED) {
+            // interpolate_2d for the chunk IRs of this pass (apply_hrtf.py:219-279), taps seg0 .. seg0+Lseg:
+            // a lane owns two adjacent taps; h goes to (h0_L | h0_R) of its chunk slot
+            // Software-pipelined over rows: the loads of row i+1 are requested before row i is folded.
+            // Rows past the end repeat the last row; lanes past the end evaluate a clamped tap and
+            // simply do not store, so the loop body has no divergent branch.
+            const int m = seg0 + 2 * lane;
+            const int m_c = m < A.L - 1 ? m : (A.L > 1 ? A.L - 2 : 0);
+            const int n_iter = (n_hrows + HD_NW - 1) / HD_NW;
+            auto store_row = [&](int i, f32x2 h) {
+                int r = wv + HD_NW * i;
+                if (r > n_hrows - 1) r = n_hrows - 1;
+                if (m != m_c) {                              // only when the pair straddles or passes L
+                    h.x = (m == A.L - 1) ? h.y : 0.f;        // m = L-1: the clamped pair is (L-2, L-1)
+                    h.y = 0.f;                               // taps >= L read as zero
+                }
+                if (2 * lane < Lseg) {
+                    float *dst = hd + (r >> 1) * HD_SLOT + 8 * lane + (r & 1);
+                    dst[0] = h.x;
+                    dst[4] = h.y;
+                }
+            };
+            f32x2 va[16], vb[16];
+            plan_eval_issue(A.packed, pword[0], m_c, A.L, A.U, va);
+#pragma unroll
+            for (int i = 0; i < HD_MAXEVAL; i += 2) {
+                if (i < n_iter) {                            // uniform
+                    if (i + 1 < n_iter) plan_eval_issue(A.packed, pword[i + 1 < HD_MAXEVAL ? i + 1 : i], m_c, A.L, A.U, vb);
+                    store_row(i, plan_eval_finish(pword[i], va));
+                    if (i + 1 < n_iter) {
+                        if (i + 2 < n_iter) plan_eval_issue(A.packed, pword[i + 2 < HD_MAXEVAL ? i + 2 : i], m_c, A.L, A.U, va);
+                        store_row(i + 1, plan_eval_finish(pword[i + 1 < HD_MAXEVAL ? i + 1 : i], vb));
+                    }
+                }
+            }
+            __syncthreads();
+            // d = H_{c+1} - H_c next to h0 (slot nslots only lends its h0)
+            for (int i = tid; i < nslots * RT_SEG; i += HD_THREADS) {
+                const int slot = i >> 7, t = i & (RT_SEG - 1);
+                if (t < Lseg) {
+                    f32x4 *p4 = reinterpret_cast<f32x4 *>(hd) + slot * (HD_SLOT / 4) + t;
+                    const f32x4 a = p4[0], b = p4[HD_SLOT / 4];
+                    reinterpret_cast<f32x2 *>(p4)[1] = f32x2{b.x - a.x, b.y - a.y};
+                }
+            }
+        } else if (tap < Lseg) {
             const float live = seg0 + tap < A.L ? 1.0f : 0.0f;   // taps >= L read as zero
             f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tap;
 #pragma unroll
@@ -817,7 +881,7 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     if (kind == KIND_HD) {
         p.tile = HD_TILE;
         p.hd_slots = hd_slots;
-        p.lds_bytes = (size_t)(HD_X_FLOATS + hd_slots * HD_SLOT) * sizeof(float);
+        p.lds_bytes = (size_t)(HD_X_FLOATS + (hd_slots + 1) * HD_SLOT) * sizeof(float);   // +1: fused h0 of the last chunk
         wg_per_cu = (long)(160 * 1024 / p.lds_bytes);
         if (wg_per_cu > 2) wg_per_cu = 2;
         if (wg_per_cu < 1) wg_per_cu = 1;
@@ -871,7 +935,9 @@ extern "C" const char *bas_render_kernel_name(int n_src, long T_in, int K, int S
 
 static int render_mix_impl(const float *x, long x_stride, const float *H, int n_src, long T_in, int K, int S,
                            int L, float *y, int accumulate, float *peak, void *ws, size_t ws_bytes,
-                           bas_stream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                           bas_stream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end,
+                           const float *packed = nullptr, const void *plans = nullptr, int U = 0) {
+    const bool fused = packed != nullptr;
     BAS_REQUIRE(y, BAS_E_NULL, "bas_render_mix_f32: y is null");
     BAS_REQUIRE(n_src >= 0 && T_in >= 0 && K > 0 && S > 0 && L > 0, BAS_E_SHAPE,
                 "bas_render_mix_f32: need n_src>=0, T_in>=0, K,S,L>0 (n_src=%d T_in=%ld K=%d S=%d L=%d)",
@@ -880,7 +946,8 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
                 "bas_render_mix_f32: subchunksize does not divide chunksize evenly (K=%d S=%d)", K, S);
     BAS_REQUIRE(T_in % K == 0, BAS_E_SHAPE, "bas_render_mix_f32: T_in (%ld) must be a multiple of K (%d)", T_in,
                 K);
-    BAS_REQUIRE(n_src == 0 || T_in == 0 || (x && H), BAS_E_NULL, "bas_render_mix_f32: x or H is null");
+    BAS_REQUIRE(n_src == 0 || T_in == 0 || (x && (H || (packed && plans))), BAS_E_NULL,
+                "bas_render_mix_f32: x or H (fused: packed, plans) is null");
     BAS_REQUIRE(n_src == 0 || x_stride >= T_in, BAS_E_SHAPE, "bas_render_mix_f32: x_stride < T_in");
     BAS_REQUIRE(T_in / K < (1L << 30), BAS_E_SHAPE, "bas_render_mix_f32: too many chunks");
     hipStream_t st = bas_stream(stream);
@@ -893,8 +960,12 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     const int n_chunks = (int)(T_in / K);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (x_stride % 4 == 0) &&
                          (reinterpret_cast<uintptr_t>(ws) % 16 == 0) && (reinterpret_cast<uintptr_t>(H) % 8 == 0);
+    (void)fused;
     const int live_src = T_in == 0 ? 0 : n_src;
     RenderPlan p = plan_render(live_src, T_in, K, S, L, aligned);
+    BAS_REQUIRE(!fused || live_src == 0 || p.kind == KIND_HD, BAS_E_SHAPE,
+                "bas_render_mix_fused_f32: sizes/alignment not served by the fused kernel "
+                "(bas_render_fused_supported); use bas_interp2d_f32 + bas_render_mix_f32");
     if (p.kind == KIND_GENERIC) {
         if (ev_begin) (void)hipEventRecord(ev_begin, st);
         hipLaunchKernelGGL(bas_render_generic_kernel, dim3(grid_for(T_out, 8192)), dim3(256), 0, st, x, x_stride,
@@ -910,13 +981,17 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     A.units_total = p.units_total; A.units_per_wg = p.units_per_wg; A.parts_per_wg = p.parts_per_wg;
     A.slab = reinterpret_cast<float *>(ws);
     { const char *d = getenv("BAS_DEBUG_FLAGS"); A.dbg = d ? atoi(d) : 0; }
-    const void *fn = p.kind == KIND_HD ? reinterpret_cast<const void *>(bas_render_hd_kernel)
+    A.packed = packed; A.plans = reinterpret_cast<const int *>(plans); A.U = U;
+    const void *fn = p.kind == KIND_HD ? (fused ? reinterpret_cast<const void *>(bas_render_hd_kernel<true>)
+                                                : reinterpret_cast<const void *>(bas_render_hd_kernel<false>))
                                         : reinterpret_cast<const void *>(bas_render_rows32_kernel);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
-    if (p.kind == KIND_HD)
-        hipLaunchKernelGGL(bas_render_hd_kernel, dim3(p.n_wg), dim3(HD_THREADS), p.lds_bytes, st, A, p.hd_slots);
+    if (p.kind == KIND_HD && fused)
+        hipLaunchKernelGGL(bas_render_hd_kernel<true>, dim3(p.n_wg), dim3(HD_THREADS), p.lds_bytes, st, A, p.hd_slots);
+    else if (p.kind == KIND_HD)
+        hipLaunchKernelGGL(bas_render_hd_kernel<false>, dim3(p.n_wg), dim3(HD_THREADS), p.lds_bytes, st, A, p.hd_slots);
     else
         hipLaunchKernelGGL(bas_render_rows32_kernel, dim3(p.n_wg), dim3(RT_THREADS), p.lds_bytes, st, A);
     if (ev_end) (void)hipEventRecord(ev_end, st);
@@ -941,6 +1016,24 @@ extern "C" int bas_render_mix_profiled_f32(const float *x, long x_stride, const 
                                            void *ev_end) {
     return render_mix_impl(x, x_stride, H, n_src, T_in, K, S, L, y, accumulate, peak, ws, ws_bytes, stream,
                            reinterpret_cast<hipEvent_t>(ev_begin), reinterpret_cast<hipEvent_t>(ev_end));
+}
+
+extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L) {
+    if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return 0;
+    return plan_render(n_src, T_in, K, S, L, true).kind == KIND_HD ? 1 : 0;
+}
+
+extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed, const void *plans,
+                                        int n_src, long T_in, int K, int S, int L, int U, float *y,
+                                        int accumulate, float *peak, void *ws, size_t ws_bytes,
+                                        bas_stream_t stream, void *ev_begin, void *ev_end) {
+    BAS_REQUIRE(packed && plans, BAS_E_NULL, "bas_render_mix_fused_f32: packed or plans is null");
+    BAS_REQUIRE(U > 0, BAS_E_SHAPE, "bas_render_mix_fused_f32: U must be positive");
+    BAS_REQUIRE(reinterpret_cast<uintptr_t>(plans) % 16 == 0, BAS_E_ALIGN,
+                "bas_render_mix_fused_f32: plans must be 16-byte aligned");
+    return render_mix_impl(x, x_stride, nullptr, n_src, T_in, K, S, L, y, accumulate, peak, ws, ws_bytes, stream,
+                           reinterpret_cast<hipEvent_t>(ev_begin), reinterpret_cast<hipEvent_t>(ev_end), packed,
+                           plans, U);
 }
 
 extern "C" int bas_peak_normalize_f32(float *y, long n, float *peak, int apply, bas_stream_t stream) {

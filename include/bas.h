@@ -128,6 +128,26 @@ int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, i
                                 float *peak, void *ws, size_t ws_bytes, bas_stream_t stream,
                                 void *ev_begin, void *ev_end);
 
+/* ---- a6 + a7 fused: chunk IRs evaluated inside the FIR kernel ------------------
+ * bas_interp2d_plan_f32 runs only the per-(query, ear) plan step of bas_interp2d_f32
+ * (delays, shift splits, the 16 folded blend weights; apply_hrtf.py:219-279) and
+ * leaves n*2 plans of 128 bytes in `plans` (bas_interp2d_workspace_bytes(n) bytes,
+ * 16-byte aligned; query order [n_src][T_in/K + 1]).  bas_render_mix_fused_f32 is
+ * bas_render_mix_f32 with H replaced by (packed table, plans): every workgroup
+ * evaluates the chunk IRs it needs while staging, so the [n][2][L] IR array never
+ * exists in HBM.  Served by the fast kernel only: check bas_render_fused_supported
+ * (1 = yes) and otherwise use bas_interp2d_f32 + bas_render_mix_f32.  ev_begin/ev_end:
+ * optional hipEvent_t pair recorded around the FIR kernel (may be NULL). */
+int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double *w, int n,
+                          int ndir, int L, int U, void *plans, size_t plans_bytes,
+                          bas_stream_t stream);
+int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L);
+int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed,
+                             const void *plans, int n_src, long T_in, int K, int S, int L,
+                             int U, float *y, int accumulate, float *peak, void *ws,
+                             size_t ws_bytes, bas_stream_t stream, void *ev_begin,
+                             void *ev_end);
+
 /* ---- a7 (vii): peak normalisation (apply_hrtf.py:462-464) -------------------
  * m = max|y| over n floats; *peak = m (device float, may be NULL when apply);
  * if apply and m > 1: y /= m. */
