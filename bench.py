@@ -8,8 +8,7 @@ Workload (config 4 of BASELINE.json, per GPU): 256 concurrent moving sources x 1
 44.1 kHz mono, chunk K=512, subchunk S=32, IR L=128 taps (samples_to_keep=128, U=8),
 synthetic table + seeded noise + per-source spiral/circle trajectories,
 mixed to one stereo pair.  One "step" = one full pass of the hot path over that batch
-with inputs resident in HBM: bas_interp2d_plan_f32 (read plans of all chunk IRs) -> bas_render_mix_fused_f32
-(chunk IRs evaluated from the table inside the FIR kernel; time-varying FIR + overlap-add + mix +
+with inputs resident in HBM: bas_interp2d_f32 (all chunk IRs) -> bas_render_mix_f32 (time-varying FIR + overlap-add + mix +
 fused peak) -> [N>1: one RCCL gather of the
 partial mixes to rank 0 + fixed-order sum] -> peak rule.
 
@@ -191,7 +190,7 @@ def main():
     peak = torch.empty((1,), dtype=torch.float32, device=dev)
     ev = HipEvents(args.steps)
 
-    fused = None if os.environ.get("BAS_BENCH_FUSED", "1") == "1" else False
+    fused = os.environ.get("BAS_BENCH_FUSED", "0") == "1"   # chunk IRs inside the FIR kernel (bas_render_mix_fused_f32)
 
     def step(i_event=None):
         events = None if i_event is None else ev.pairs[i_event]

@@ -14,6 +14,7 @@ Differences a caller can see (all documented in DESIGN.md):
     queries / many sources; the reference has none.
 """
 import math
+import os
 
 import numpy as np
 
@@ -217,6 +218,8 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     n_src, t_in = x.shape
     lib = _hip.lib()
     if fused is None:
+        fused = os.environ.get("BAS_FUSED", "0") == "1"
+    if fused:
         fused = bool(lib.bas_render_fused_supported(n_src, t_in, chunksize, subchunksize, tbl.L)) and \
             x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
     n_q = idx.shape[0]

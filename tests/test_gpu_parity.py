@@ -188,6 +188,24 @@ def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_sr
     assert rel_err(got, want) <= REL, (name, rel_err(got, want))
 
 
+@pytest.mark.parametrize("n_src,n,k,s,l", [(5, 20000, 512, 32, 128), (2, 9000, 1024, 64, 100), (2, 9000, 512, 32, 300)])
+def test_fused_render_equals_unfused(dev_tables, tables, n_src, n, k, s, l):
+    """bas_render_mix_fused_f32 (chunk IRs evaluated inside the FIR kernel) against the two-kernel path
+    and the oracle."""
+    if l == 300:
+        h = tables["consistent"].truncated(300)
+        d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    else:
+        h, d = dev_tables[("consistent", l)]
+    assert bas._hip.lib().bas_render_fused_supported(n_src, -(-n // k) * k, k, s, l) == 1
+    sigs, elev, azim, irs = _mix_case(h, n_src, n, k, s, seed=900)
+    want = orc.render_mix(sigs, k, s, irs)
+    fused = bas.render_sources(sigs, k, s, elev, azim, d, fused=True).cpu().numpy()
+    plain = bas.render_sources(sigs, k, s, elev, azim, d, fused=False).cpu().numpy()
+    assert rel_err(fused, want) <= REL and rel_err(plain, want) <= REL
+    assert rel_err(fused, plain) <= 2e-6
+
+
 def test_kernel_selection():
     lib = bas._hip.lib()
     assert lib.bas_render_kernel_name(256, 441344, 512, 32, 128) == b"bas_render_hd_kernel"
