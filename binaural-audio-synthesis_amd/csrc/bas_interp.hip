@@ -25,6 +25,8 @@
 //     h[m] = sum_k W_k * sample_k(m)
 // with the 16 weights W_k folded once per (query, ear) in binary64.
 #include "bas_internal.h"
+#include <stdlib.h>
+#include <string.h>
 
 // ---------------------------------------------------------------------------
 // a1: [2][ndir][M] -> [2][ndir][U][L + 2]   (plane = [last sample][L samples][first sample])
@@ -211,10 +213,10 @@ __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__
     ring_plan(top, d, e, ndir, pt, qt, at, L, U, c_top, s2);
     ring_plan(bot, d, e, ndir, pb, qb, ab, L, U, bas_submod(c_top, b3, M), s2);
     EarPlanW pl;
-    make_set(pl.set[0], bot.row_q, bot.c_q, L, U);
-    make_set(pl.set[1], bot.row_p, bot.c_p, L, U);
-    make_set(pl.set[2], top.row_q, top.c_q, L, U);
-    make_set(pl.set[3], top.row_p, top.c_p, L, U);
+    make_set(pl.set[0], bot.row_q, bot.c_q, L, U, qb);
+    make_set(pl.set[1], bot.row_p, bot.c_p, L, U, pb);
+    make_set(pl.set[2], top.row_q, top.c_q, L, U, qt);
+    make_set(pl.set[3], top.row_p, top.c_p, L, U, pt);
     // fold the blend chain into 16 weights (apply_hrtf.py:90-91, :98-99, :268-269, :276-277)
     const double cC[2] = {1.0 - (double)f4, (double)f4};
     double wrb[3], wbb[4], wbt[3];

@@ -7,7 +7,7 @@ struct SetPlan {
     int base;          // float index of plane ph0's sample 0 in `packed` (guard is at base - 1)
     int ph0;           // phase of read j = 0; reads j <= ph0 stay in plane ph0 - j at offset o,
     int o;             // reads j > ph0 continue in plane ph0 - j + U one sample earlier
-    int pad;
+    int dir;           // direction index of the table row the set reads
 };
 
 struct EarPlanW {
@@ -15,12 +15,12 @@ struct EarPlanW {
     float w[16];       // same order as the sets: 5 + 4 + 4 + 3
 };
 
-__device__ __forceinline__ void make_set(SetPlan &sp, int row, int c, int L, int U) {
+__device__ __forceinline__ void make_set(SetPlan &sp, int row, int c, int L, int U, int dir) {
     const int o = c / U, ph = c - o * U;           // c in [0, M)
     sp.base = row + ph * (L + 2) + 1;
     sp.ph0 = ph;
     sp.o = o;
-    sp.pad = 0;
+    sp.dir = dir;
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
