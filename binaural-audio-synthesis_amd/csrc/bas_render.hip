@@ -517,6 +517,8 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
     long cur_tile = first_tile;
     float *slab_wg = A.slab + (long)blockIdx.x * A.parts_per_wg * 2 * HD_TILE;
     const float invK = 1.0f / (float)A.K;
+    const unsigned prio_flip = blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u;
+    const int prio_slice = (A.dbg >> 8) & 31 ? (A.dbg >> 8) & 31 : ((A.dbg & 16) ? 0 : 12);   // default 2^12 ticks = 41 us
 
     auto flush = [&](long tile) {
         float *dst = slab_wg + (tile - first_tile) * 2 * HD_TILE + 2048 * wv + 32 * lane;
@@ -684,17 +686,28 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                 sl -= 1;
             }
         };
-        STAMP(tf0);
+#ifdef BAS_STAMPS
+        const unsigned long long tf0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int rp = 0; rp <= halo; ++rp) {
+            // Fair time slicing between the two workgroups of a CU.  The SIMD arbiter serves the older
+            // wave first, so without this the first-dispatched workgroup runs at nearly full speed,
+            // finishes ~35 % early and leaves the CU with one wave per SIMD.  Priority alternates every
+            // 2^slice_shift ticks of the 100 MHz clock, in opposite phase for the two halves of the grid
+            // (blocks b and b + grid/2 share a CU under the observed dispatch order; speed only).
+            if (prio_slice) {
+                const unsigned t = (unsigned)(__builtin_amdgcn_s_memrealtime() >> prio_slice);
+                if ((t & 1u) ^ prio_flip) __builtin_amdgcn_s_setprio(2);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             float al;
             const float *hdrow;
             step_setup(rp, al, hdrow);
             hd_row_step_masked(acc, xrow, hdrow, al, mask_of(rp));
             step_done();
         }
-        STAMP(tf1);
 #ifdef BAS_STAMPS
-        st_fir += tf1 - tf0;
+        st_fir += __builtin_amdgcn_s_memrealtime() - tf0;
 #endif
     }
     flush(cur_tile);

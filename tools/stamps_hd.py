@@ -41,4 +41,23 @@ cnt = collections.Counter(key.tolist())
 print("distinct (xcc,se,sh,cu):", len(cnt), "WGs per CU histogram:", collections.Counter(cnt.values()))
 late = st > 50
 print("WGs starting later than 50us:", int(late.sum()))
-print("fir share of duration: %.3f" % (a[:, 2].astype(np.float64).sum() / 1.0 / ((t1 - t0).sum() * 1.0) ))
+print("fir share of workgroup lifetime: %.3f" % (a[:, 2].astype(np.float64).sum() / (t1 - t0).sum()))
+order = np.argsort(en)
+print("fir share, earliest-finishing quarter: %.3f, latest quarter: %.3f" % (
+    a[order[:len(order)//4], 2].astype(np.float64).sum() / (t1 - t0)[order[:len(order)//4]].sum(),
+    a[order[-len(order)//4:], 2].astype(np.float64).sum() / (t1 - t0)[order[-len(order)//4:]].sum()))
+
+# per-CU pairs and per-XCC means
+pairs = collections.defaultdict(list)
+for i in range(a.shape[0]):
+    pairs[int(key[i])].append((float(en[i]), int(xcc[i]), i))
+first = np.array([min(v)[0] for v in pairs.values() if len(v) == 2])
+second = np.array([max(v)[0] for v in pairs.values() if len(v) == 2])
+print("per CU: first-finisher end us mean %.1f (min %.1f max %.1f); second-finisher mean %.1f (min %.1f max %.1f)" % (
+    first.mean(), first.min(), first.max(), second.mean(), second.min(), second.max()))
+for xc in range(8):
+    sel = xcc == xc
+    print("xcc", xc, "n", int(sel.sum()), "end mean %.1f" % en[sel].mean(), "min %.1f max %.1f" % (en[sel].min(), en[sel].max()))
+# is the first finisher the lower block index (dispatched first)?
+lower_first = sum(1 for v in pairs.values() if len(v) == 2 and min(v)[2] == min(x[2] for x in v))
+print("CUs where the lower blockIdx finished first:", lower_first, "of", len(pairs))
