@@ -1,0 +1,98 @@
+"""Block-wise (streaming) rendering with carried state.
+
+The reference renders one whole signal held in RAM (apply_hrtf.py:405-414) but its chunk
+loop is causal (:431-453): output sample n depends on inputs n-L+1 .. n and on the chunk
+IRs around them.  StreamRenderer therefore keeps, per source, the last `halo` input samples
+(halo = (L-1) rounded up to a multiple of the chunk size) and the interpolation parameters
+of the chunk boundaries inside that halo; every call renders [halo | new block] with the
+same kernels and emits exactly the outputs the new block completes.  Concatenating the
+emitted blocks (plus `finish()`) reproduces the whole-signal render sample for sample
+(tests/test_gpu_parity.py::test_streaming_equals_whole).
+
+The reference's peak rule (apply_hrtf.py:462-464) is global over the finished signal and
+cannot be applied to samples already handed out; the stream returns un-normalised audio
+and tracks the running peak (`peak`), so a caller can scale afterwards exactly as the
+reference would.  Long streams (BASELINE config 5: 1 h at 48 kHz, 1024 sources) never
+materialise more than one block of inputs, chunk IRs and outputs.
+"""
+import numpy as np
+
+from . import sphere
+from .apply_hrtf import as_device_table, render_params_device
+
+
+class StreamRenderer:
+    def __init__(self, tbl, n_src, chunksize, subchunksize):
+        import torch
+        assert chunksize % subchunksize == 0, 'subchunksize does not divide chunksize evenly'
+        self.tbl = as_device_table(tbl)
+        self.n_src, self.K, self.S = int(n_src), int(chunksize), int(subchunksize)
+        L = self.tbl.L
+        self.halo = -(-(L - 1) // self.K) * self.K if L > 1 else 0
+        dev = self.tbl.device
+        self._x_halo = torch.zeros((self.n_src, self.halo), dtype=torch.float32, device=dev)
+        self._idx_halo = None          # parameters at the halo's chunk boundaries, [n_src, halo/K, 4|3]
+        self._w_halo = None
+        self._idx_last = self._w_last = None
+        self.peak = 0.0
+        self.samples_in = 0
+        self._finished = False
+
+    def process(self, block, elev, azim):
+        """block: [n_src, B] (B a multiple of the chunk size); elev/azim: float64 [n_src, B/K + 1],
+        the trajectory at t = t0, t0+K, .., t0+B of this block (radians).  Returns the B stereo
+        samples this block completes as a device tensor (B, 2), un-normalised."""
+        import torch
+        assert not self._finished, "stream already finished"
+        blk = torch.as_tensor(block)
+        assert blk.dim() == 2 and blk.shape[0] == self.n_src, 'block must be [n_src, B]'
+        B = blk.shape[1]
+        assert B % self.K == 0 and B > 0, 'block length must be a positive multiple of the chunk size'
+        idx, w = sphere.interpolation_params_batch(elev, azim)
+        nb = B // self.K + 1
+        if idx.shape[:2] != (self.n_src, nb):
+            raise ValueError(f"elev/azim must have shape ({self.n_src}, {nb})")
+        dev = self.tbl.device
+        nh = self.halo // self.K
+        if self._idx_halo is None:      # first block: the halo holds silence, any valid IR will do
+            self._idx_halo = np.repeat(idx[:, :1], nh, axis=1)
+            self._w_halo = np.repeat(w[:, :1], nh, axis=1)
+        idx_all = np.concatenate([self._idx_halo, idx], axis=1)        # boundaries t0-halo .. t0+B
+        w_all = np.concatenate([self._w_halo, w], axis=1)
+        x = torch.empty((self.n_src, self.halo + B), dtype=torch.float32, device=dev)
+        x[:, :self.halo] = self._x_halo
+        x[:, self.halo:] = blk.to(device=dev, dtype=torch.float32)
+        idx_t = torch.from_numpy(np.ascontiguousarray(idx_all.reshape(-1, 4))).to(dev)
+        w_t = torch.from_numpy(np.ascontiguousarray(w_all.reshape(-1, 3))).to(dev)
+        y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_t, w_t, normalize="none")
+        out = y[:, self.halo:self.halo + B]
+        # carry: last `halo` inputs and the parameters of their chunk boundaries (t0+B-halo .. t0+B-K)
+        if self.halo:
+            self._x_halo = x[:, B:B + self.halo].clone()
+            self._idx_halo = idx_all[:, nb - 1:nb - 1 + nh].copy()
+            self._w_halo = w_all[:, nb - 1:nb - 1 + nh].copy()
+        self._idx_last, self._w_last = idx[:, -1:].copy(), w[:, -1:].copy()     # boundary t0 + B
+        self.peak = max(self.peak, float(out.abs().max())) if out.numel() else self.peak
+        self.samples_in += B
+        return out.t()
+
+    def finish(self):
+        """Emit the last L-1 samples (the tail the reference appends, apply_hrtf.py:410): render one
+        silent chunk behind the stream.  The chunk boundary at the stream's end was supplied by the
+        last process() call; the one after it only multiplies silence."""
+        import torch
+        assert not self._finished, "stream already finished"
+        if self._idx_last is None:
+            raise RuntimeError("finish() before any block")
+        L = self.tbl.L
+        dev = self.tbl.device
+        idx_all = np.concatenate([self._idx_halo, self._idx_last, self._idx_last], axis=1)
+        w_all = np.concatenate([self._w_halo, self._w_last, self._w_last], axis=1)
+        x = torch.cat([self._x_halo, torch.zeros((self.n_src, self.K), dtype=torch.float32, device=dev)], dim=1)
+        idx_t = torch.from_numpy(np.ascontiguousarray(idx_all.reshape(-1, 4))).to(dev)
+        w_t = torch.from_numpy(np.ascontiguousarray(w_all.reshape(-1, 3))).to(dev)
+        y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_t, w_t, normalize="none")
+        out = y[:, self.halo:self.halo + L - 1]
+        self.peak = max(self.peak, float(out.abs().max())) if out.numel() else self.peak
+        self._finished = True
+        return out.t()

@@ -252,3 +252,58 @@ def test_linearity_and_determinism_at_full_size(dev_tables):
                   for i in range(n_src))
     assert float((ya - singles).abs().max()) / float(ya.abs().max()) <= 2e-6
     assert ya.shape == (in_length + 127, 2)
+
+
+@pytest.mark.parametrize("l,k,s,blocks", [(128, 512, 32, (4096, 512, 8192, 1024)), (100, 512, 64, (2048, 2048)),
+                                          (300, 512, 32, (1024, 3072)), (128, 128, 32, (1280, 2560))])
+def test_streaming_equals_whole(dev_tables, tables, l, k, s, blocks):
+    """blocks rendered with carried state concatenate to the whole-signal render."""
+    import torch
+    if l == 300:
+        h = tables["consistent"].truncated(300)
+        d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    else:
+        h, d = dev_tables[("consistent", l)]
+    n_src, n = 3, sum(blocks)
+    sigs = np.stack([bas.synth.integer_noise(40 + i, n, 0.1) for i in range(n_src)])
+    t = np.arange(0, n + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        tr = bas.synth.trajectory(("spiral", "circle_askew", "passing")[i], period_s=0.07, length_s=n / 44100, turns=3.0)
+        elev[i], azim[i] = tr(t)
+    whole = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none")
+    st = bas.StreamRenderer(d, n_src, k, s)
+    outs, pos = [], 0
+    for b in blocks:
+        c0, c1 = pos // k, (pos + b) // k
+        outs.append(st.process(sigs[:, pos:pos + b], elev[:, c0:c1 + 1], azim[:, c0:c1 + 1]))
+        pos += b
+    outs.append(st.finish())
+    got = torch.cat(outs, dim=0)
+    assert got.shape == whole.shape == (n + l - 1, 2)
+    assert rel_err(got.cpu().numpy(), whole.cpu().numpy()) <= 1e-6
+    assert abs(st.peak - float(whole.abs().max())) <= 1e-6 * st.peak
+    # and the whole-signal render is right
+    irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(t.size)]) for i in range(n_src)]
+    assert rel_err(whole.cpu().numpy(), orc.render_mix(sigs, k, s, irs, normalize=False)) <= REL
+
+
+def test_cli_harness(tmp_path, tables):
+    """WAV in -> WAV out with the reference's naming, presets and normalisation."""
+    import scipy.io.wavfile as wavfile
+    from binaural_audio_synthesis_amd import cli
+    fs, n = 44100, 9000
+    pcm = (bas.synth.integer_noise(77, n, 0.3) * 32767).astype(np.int16)
+    stereo = np.stack([pcm, pcm[::-1]], axis=1)
+    src = str(tmp_path / "in.wav")
+    wavfile.write(src, fs, stereo)
+    out = cli.main([src, "--synthetic", "--trajectory", "circle_askew"])
+    assert out.endswith("in-c512-s32-l100.wav")
+    fs2, got = wavfile.read(out)
+    assert fs2 == fs and got.dtype == np.float32 and got.shape == (9216 + 99, 2)
+    # same thing through the oracle, with the CLI's own lambda (python-float branch of sphere.py)
+    y = stereo.astype(np.float32) / stereo.max()
+    mono = 0.5 * y[:, 0] + 0.5 * y[:, 1]
+    want = orc.render(mono, 512, 32, cli.presets(fs)["circle_askew"], tables["consistent"].truncated(100))
+    assert rel_err(got, want) <= REL
