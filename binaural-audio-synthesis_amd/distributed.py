@@ -76,3 +76,69 @@ def render_sources_sharded(signals, chunksize, subchunksize, elev, azim, tbl, gr
         render_fn = lambda s, k, ss, e, a, t: render_sources(s, k, ss, e, a, t, normalize="none")   # noqa: E731
     local = render_fn(signals, chunksize, subchunksize, elev, azim, tbl)
     return gather_mix(local.t(), group=group, dst=dst, mix_fn=mix_fn, scale_fn=scale_fn, normalize=normalize)
+
+
+# --------------------------------------------------------------------------
+# by time: one long scene, every rank renders ALL sources over its own time range
+# --------------------------------------------------------------------------
+def shard_time(n_chunks, world_size, rank):
+    """Chunk range [c0, c1) owned by `rank` (balanced, contiguous)."""
+    base, extra = divmod(n_chunks, world_size)
+    c0 = rank * base + min(rank, extra)
+    return c0, c0 + base + (1 if rank < extra else 0)
+
+
+def render_time_sharded(signals, chunksize, subchunksize, elev, azim, tbl, ir_length, group=None, dst=0,
+                        normalize="mix", render_fn=None, scale_fn=None):
+    """Every rank holds the whole (padded) scene description but renders only outputs
+    [c0*K, c1*K) (the last rank also the L-1 tail): it reads its inputs with a halo of
+    ceil((L-1)/K) chunks on the left, exactly like StreamRenderer, so slices need no seam
+    addition.  The slices meet in ONE gather on rank dst (disjoint ranges: concatenation),
+    followed by the peak rule over the whole signal.
+
+    signals [n_src, N]; elev/azim float64 [n_src, n_chunks+1] for the padded length.
+    render_fn(signals, K, S, elev, azim, tbl) -> un-normalised (T_out, 2); default HIP renderer.
+    Returns (T_out, 2) on rank dst, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+    if render_fn is None:
+        from .apply_hrtf import render_sources
+        render_fn = lambda s, k, ss, e, a, t: render_sources(s, k, ss, e, a, t, normalize="none")   # noqa: E731
+    scale_fn = scale_fn or (lambda y, peak: _hip_scale_by_peak(y.contiguous(), peak))
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    K, L = chunksize, ir_length
+    sig = torch.as_tensor(signals)
+    n_src, n = sig.shape
+    n_chunks = -(-n // K)
+    halo_c = -(-(L - 1) // K) if L > 1 else 0
+    c0, c1 = shard_time(n_chunks, world, rank)
+    h0 = max(c0 - halo_c, 0)                                  # first chunk read
+    x = sig[:, h0 * K:min(c1 * K, n)]
+    if x.shape[1] < (c1 - h0) * K:                            # pad the scene's last chunk (apply_hrtf.py:405-406)
+        x = torch.cat([x, torch.zeros((n_src, (c1 - h0) * K - x.shape[1]), dtype=x.dtype, device=x.device)], dim=1)
+    e = np.asarray(elev)[:, h0:c1 + 1]
+    a = np.asarray(azim)[:, h0:c1 + 1]
+    y = render_fn(x, K, subchunksize, e, a, tbl)              # ((c1-h0)*K + L-1, 2), complete from (c0-h0)*K on
+    lo = (c0 - h0) * K
+    hi = (c1 - h0) * K + (L - 1 if rank == world - 1 else 0)
+    mine = y[lo:hi].contiguous()
+    if world == 1:
+        full = mine
+    else:
+        sizes = [(shard_time(n_chunks, world, r)[1] - shard_time(n_chunks, world, r)[0]) * K +
+                 (L - 1 if r == world - 1 else 0) for r in range(world)]
+        pad = max(sizes)
+        buf = torch.zeros((pad, 2), dtype=mine.dtype, device=mine.device)
+        buf[:mine.shape[0]] = mine
+        if rank == dst:
+            parts = [torch.empty_like(buf) for _ in range(world)]
+            dist.gather(buf, gather_list=parts, dst=dst, group=group)
+            full = torch.cat([parts[r][:sizes[r]] for r in range(world)], dim=0)
+        else:
+            dist.gather(buf, gather_list=None, dst=dst, group=group)
+            return None
+    if normalize == "mix":
+        peak = full.abs().max().reshape(1)
+        full = scale_fn(full, peak)
+    return full

@@ -79,6 +79,39 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+def _worker_time(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host, sigs, elev, azim = _scene()
+    y = bas.distributed.render_time_sharded(sigs, K, S, elev, azim, None, L, render_fn=_cpu_render(host),
+                                            scale_fn=_cpu_scale)
+    if rank == 0:
+        np.save(out_path, y.numpy())
+    else:
+        assert y is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_time_partition():
+    for n, w in ((863, 8), (6, 2), (3, 4), (337500, 8)):
+        r = [bas.distributed.shard_time(n, w, k) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def test_two_rank_time_sharding_matches_single_process(tmp_path):
+    """SURVEY 8e "by time": rank g renders its output range with an input halo; one gather of disjoint slices."""
+    out = str(tmp_path / "yt.npy")
+    mp.spawn(_worker_time, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    host, sigs, elev, azim = _scene()
+    irs = [np.stack([orc.interp2d(host, elev[i, c], azim[i, c]) for c in range(elev.shape[1])]) for i in range(N_SRC)]
+    want = orc.render_mix(sigs, K, S, irs)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() / np.abs(want).max() < 1e-6
+
+
 def test_shard_sources_partition():
     for n, w in ((256, 8), (5, 2), (3, 4), (0, 2), (1024, 8)):
         got = [i for r in range(w) for i in bas.distributed.shard_sources(n, w, r)]
