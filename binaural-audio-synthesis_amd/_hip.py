@@ -21,6 +21,8 @@ SIGNATURES = {
     "bas_delay_signal_f32": (_c_int, [_c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_void_p, _c_void_p]),
     "bas_ring_interp_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                      _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
+    "bas_traj_params_f64": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                     _c_void_p, _c_void_p, _c_void_p]),
     "bas_interp2d_workspace_bytes": (_c_size_t, [_c_int]),
     "bas_interp2d_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),

@@ -367,3 +367,84 @@ extern "C" int bas_ring_interp_f32(const float *packed, const double *diffs, con
                        alpha, n, ndir, L, U, step, Mout, out, delays);
     return bas_check_launch("bas_ring_interp_f32");
 }
+
+// ---------------------------------------------------------------------------
+// a3 + elevation bracket on the device: (elev, azim) -> (idx, w)
+// ---------------------------------------------------------------------------
+// Float64 branch of sphere.azim_to_interpolation_params (sphere.py:78-121) and of interpolate_2d's
+// bracket (apply_hrtf.py:199-215, :261-266), same arithmetic as the host's
+// sphere.interpolation_params_batch: node angles are the float32 table values, comparisons run in
+// binary64, the interval width is a float32 subtraction, weights are binary64 divisions.
+// `rings` (host-computed, so both sides use identical constants):
+//   ring_elev[10] f64 = deg2rad(-45..90), ring_start[10], ring_count[10] int32, node_az[187] f32.
+struct RingTable {
+    double ring_elev[10];
+    int ring_start[10];
+    int ring_count[10];
+};
+
+__device__ __forceinline__ void ring_lookup(const RingTable &R, const float *__restrict__ node_az, int ring,
+                                             double az, int &before, int &after, double &a) {
+    if (ring == 9) {                                         // pole: sphere.py:92-93
+        before = after = 186;
+        a = 0.0;
+        return;
+    }
+    const int start = R.ring_start[ring], count = R.ring_count[ring];
+    int j = 0;                                               // last node <= az (node 0 is azimuth 0)
+    for (int i = 1; i < count; ++i)
+        if ((double)node_az[start + i] <= az) j = i;
+    const bool wrap = j + 1 >= count;
+    const float b32 = node_az[start + j];
+    const float a32 = wrap ? (float)(2.0 * 3.14159265358979323846) : node_az[start + j + 1];
+    const float den = __fsub_rn(a32, b32);                   // float32 subtraction, as sphere.py:119 evaluates it
+    before = start + j;
+    after = wrap ? start : start + j + 1;
+    a = (az - (double)b32) / (double)den;
+}
+
+__global__ __launch_bounds__(256) void bas_traj_params_kernel(const double *__restrict__ elev,
+                                                                const double *__restrict__ azim, long n,
+                                                                RingTable R, const float *__restrict__ node_az,
+                                                                int32_t *__restrict__ idx,
+                                                                double *__restrict__ w) {
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    for (long q = blockIdx.x * 256L + threadIdx.x; q < n; q += (long)gridDim.x * 256L) {
+        const double e = elev[q];
+        double z = fmod(azim[q], two_pi);                    // numpy's % : result in [0, 2 pi)
+        if (z != 0.0 && z < 0.0) z += two_pi;
+        int hi = 0, lo = 9;                                  // first elevation >= e, last elevation <= e
+        while (hi < 9 && R.ring_elev[hi] < e) ++hi;
+        while (lo > 0 && R.ring_elev[lo] > e) --lo;
+        int tb, taf, bb, baf;
+        double ta, ba;
+        ring_lookup(R, node_az, hi, z, tb, taf, ta);
+        ring_lookup(R, node_az, lo, z, bb, baf, ba);
+        const double span = R.ring_elev[hi] - R.ring_elev[lo];
+        const double a = span > 0.0 ? (e - R.ring_elev[lo]) / span : 0.0;
+        idx[4 * q + 0] = tb; idx[4 * q + 1] = taf; idx[4 * q + 2] = bb; idx[4 * q + 3] = baf;
+        w[3 * q + 0] = ta; w[3 * q + 1] = ba; w[3 * q + 2] = a;
+    }
+}
+
+extern "C" int bas_traj_params_f64(const double *elev, const double *azim, long n, const double *ring_elev,
+                                   const int32_t *ring_start, const int32_t *ring_count, const float *node_az,
+                                   int32_t *idx, double *w, bas_stream_t stream) {
+    BAS_REQUIRE(ring_elev && ring_start && ring_count && node_az, BAS_E_NULL, "bas_traj_params_f64: null ring table");
+    BAS_REQUIRE(n >= 0, BAS_E_SHAPE, "bas_traj_params_f64: n < 0");
+    if (n == 0) return 0;
+    BAS_REQUIRE(elev && azim && idx && w, BAS_E_NULL, "bas_traj_params_f64: null pointer");
+    RingTable R;
+    for (int i = 0; i < 10; ++i) {
+        R.ring_elev[i] = ring_elev[i];
+        R.ring_start[i] = ring_start[i];
+        R.ring_count[i] = ring_count[i];
+        BAS_REQUIRE(R.ring_count[i] > 0 && R.ring_start[i] >= 0 && R.ring_start[i] + R.ring_count[i] <= 187,
+                    BAS_E_SHAPE, "bas_traj_params_f64: ring %d out of the 187-direction table", i);
+    }
+    long blocks = (n + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bas_traj_params_kernel, dim3((unsigned)blocks), dim3(256), 0, bas_stream(stream), elev, azim,
+                       n, R, node_az, idx, w);
+    return bas_check_launch("bas_traj_params_f64");
+}

@@ -157,3 +157,32 @@ def interpolation_params_batch(elev, azim):
     idx = np.stack([tb, taf, bb, baf], axis=-1).astype(np.int32).reshape(shape + (4,))
     w = np.stack([ta, ba, a], axis=-1).reshape(shape + (3,))
     return idx, w
+
+
+_DEVICE_NODES = {}
+
+
+def interpolation_params_device(elev, azim):
+    """interpolation_params_batch on the GPU (bas_traj_params_f64): elev/azim are float64 device
+    tensors of equal shape; returns device tensors idx int32 [..., 4], w float64 [..., 3].
+    Non-finite angles are not diagnosed here (the host form raises ValueError)."""
+    import ctypes
+    import torch
+    from . import _hip
+    assert elev.is_cuda and elev.dtype == torch.float64 and azim.shape == elev.shape and azim.dtype == torch.float64
+    dev = elev.device
+    nodes = _DEVICE_NODES.get(dev.index)
+    if nodes is None:
+        nodes = _DEVICE_NODES[dev.index] = torch.from_numpy(index_elev_azim[:, 2].copy()).to(dev)
+    e = elev.contiguous().reshape(-1)
+    z = azim.contiguous().reshape(-1)
+    n = e.numel()
+    idx = torch.empty((n, 4), dtype=torch.int32, device=dev)
+    w = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    ring_elev = (ctypes.c_double * 10)(*[float(v) for v in _AVAILABLE_ELEVS])
+    ring_start = (ctypes.c_int32 * 10)(*RING_START)
+    ring_count = (ctypes.c_int32 * 10)(*RING_COUNTS)
+    _hip.call("bas_traj_params_f64", _hip.ptr(e), _hip.ptr(z), n, ctypes.addressof(ring_elev),
+              ctypes.addressof(ring_start), ctypes.addressof(ring_count), _hip.ptr(nodes), _hip.ptr(idx), _hip.ptr(w),
+              _hip.current_stream(dev))
+    return idx.reshape(tuple(elev.shape) + (4,)), w.reshape(tuple(elev.shape) + (3,))

@@ -81,6 +81,20 @@ int bas_ring_interp_f32(const float *packed, const double *diffs, const int32_t 
                         int return_upsampled, float *out, double *delays,
                         bas_stream_t stream);
 
+/* ---- a3 + elevation bracket on the device --------------------------------------
+ * (elev, azim) radians -> the (idx, w) inputs of bas_interp2d_f32, float64 branch of
+ * sphere.azim_to_interpolation_params (sphere.py:78-121) plus interpolate_2d's elevation
+ * bracket and vertical weight (apply_hrtf.py:199-215, :261-266); azimuth wrapped,
+ * elevation clamped like the reference.  Same arithmetic as the host's
+ * sphere.interpolation_params_batch (bit-identical on finite inputs; tested).
+ *   elev, azim [n] f64 (device); idx [n][4] int32, w [n][3] f64 (device)
+ *   ring_elev[10] f64, ring_start[10], ring_count[10] int32: HOST arrays (the ten rings:
+ *   deg2rad(-45..90), first direction index, number of azimuths); node_az [187] f32
+ *   DEVICE array of the table's node azimuths (sphere.py:318 float32 values). */
+int bas_traj_params_f64(const double *elev, const double *azim, long n, const double *ring_elev,
+                        const int32_t *ring_start, const int32_t *ring_count, const float *node_az,
+                        int32_t *idx, double *w, bas_stream_t stream);
+
 /* ---- a6: interpolate_2d (apply_hrtf.py:171-281), batched --------------------
  * The angle -> (indices, weights) step (sphere.py:78-121 and the elevation
  * bracket apply_hrtf.py:199-215, :261-266) is host logic; this entry point does

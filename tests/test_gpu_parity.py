@@ -307,3 +307,21 @@ def test_cli_harness(tmp_path, tables):
     mono = 0.5 * y[:, 0] + 0.5 * y[:, 1]
     want = orc.render(mono, 512, 32, cli.presets(fs)["circle_askew"], tables["consistent"].truncated(100))
     assert rel_err(got, want) <= REL
+
+
+def test_device_params_kernel_is_bit_identical_to_host():
+    """bas_traj_params_f64 against sphere.interpolation_params_batch, incl. nodes +- eps,
+    negative / large azimuths, clamped elevations and the pole."""
+    import torch
+    g = golden("interp2d.npz")
+    gp = golden("azim_params.npz")
+    rng = np.random.default_rng(12)
+    e = np.concatenate([g["points"][:, 0], gp["elev"], rng.uniform(-1.4, 2.0, 200000)])
+    z = np.concatenate([g["points"][:, 1], gp["azim"], rng.uniform(-50, 100, 200000)])
+    nodes = np.deg2rad(np.arange(0, 361, 15, dtype=np.float64))
+    e = np.concatenate([e, np.repeat(np.deg2rad(np.array([-45., 0., 37., 60., 75., 90.])), nodes.size * 3)])
+    z = np.concatenate([z, np.tile(np.concatenate([nodes, nodes + 1e-12, nodes - 1e-12]), 6)])
+    idx_h, w_h = bas.sphere.interpolation_params_batch(e, z)
+    idx_d, w_d = bas.sphere.interpolation_params_device(torch.from_numpy(e).cuda(), torch.from_numpy(z).cuda())
+    assert np.array_equal(idx_d.cpu().numpy(), idx_h)
+    assert np.array_equal(w_d.cpu().numpy(), w_h)
