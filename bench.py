@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--subchunk", type=int, default=32)
     ap.add_argument("--taps", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["scene", "stream"], default="scene",
+                    help="scene = the contract's benchmark (default); stream = BASELINE config 5 shape: long stream "
+                         "rendered block by block with carried state, inputs and trajectories generated on the device")
+    ap.add_argument("--fs", type=int, default=FS)
+    ap.add_argument("--block", type=int, default=262144, help="stream mode: input samples per block")
     ap.add_argument("--cpu-sources-per-core", type=int, default=16)
     return ap.parse_args()
 
@@ -134,8 +139,55 @@ class HipEvents:
         return ms.value
 
 
+def stream_mode(args):
+    """BASELINE config 5 (1024 sources, 48 kHz, hours of audio) in miniature: `steps` blocks of `block`
+    samples through StreamRenderer; nothing but one block of inputs, chunk IRs and outputs is ever resident,
+    and the trajectory -> parameter step runs on the device.  One JSON line, not the contract's metric."""
+    import math
+    import torch
+    import binaural_audio_synthesis_amd as bas
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    n_src, k, s, l, fs, B = args.sources, args.chunk, args.subchunk, args.taps, args.fs, args.block
+    host = bas.synth.make_table("consistent", 0).truncated(l)
+    tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left, host.irs_right,
+                                 device=dev)
+    st = bas.StreamRenderer(tbl, n_src, k, s)
+    src = torch.arange(n_src, dtype=torch.float64, device=dev)[:, None]
+    phase = 2 * math.pi * src / n_src
+    period = (2.0 + (src % 256) / 64.0) * fs
+    gen = torch.Generator(device=dev).manual_seed(5)
+
+    def block(i):
+        t = (torch.arange(B // k + 1, dtype=torch.float64, device=dev)[None, :] * k + i * B)
+        elev = (math.pi / 4) * torch.cos(2 * math.pi * t / period + phase)          # askew circles, per-source period
+        azim = 2 * math.pi * t / period + phase
+        x = (torch.rand((n_src, B), generator=gen, device=dev) * 2 - 1) * (1.0 / n_src)
+        return x, elev, azim
+
+    for i in range(args.warmup):
+        st.process(*block(i))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        y = st.process(*block(i))
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    audio_s = args.steps * B / fs
+    print(json.dumps({"metric": "streaming render, x real-time", "value": audio_s / el, "unit": "x real-time",
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+                      "higher_is_better": True, "dtype": "f32", "data": "synthetic (generated on device, included in time)",
+                      "config": {"workload": f"BASELINE config 5 shape: {n_src} sources @ {fs} Hz streamed in blocks of {B} "
+                                             f"samples, chunk {k}, subchunk {s}, {l} taps", "block": B},
+                      "source_samples_per_s": n_src * B * args.steps / el,
+                      "hour_of_audio_seconds": 3600.0 / (audio_s / el), "peak": st.peak,
+                      "out_block_shape": list(y.shape)}), flush=True)
+
+
 def main():
     args = parse()
+    if args.mode == "stream":
+        return stream_mode(args)
     import numpy as np
     import torch
     import torch.distributed as dist

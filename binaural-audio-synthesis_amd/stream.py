@@ -15,8 +15,6 @@ and tracks the running peak (`peak`), so a caller can scale afterwards exactly a
 reference would.  Long streams (BASELINE config 5: 1 h at 48 kHz, 1024 sources) never
 materialise more than one block of inputs, chunk IRs and outputs.
 """
-import numpy as np
-
 from . import sphere
 from .apply_hrtf import as_device_table, render_params_device
 
@@ -34,7 +32,7 @@ class StreamRenderer:
         self._idx_halo = None          # parameters at the halo's chunk boundaries, [n_src, halo/K, 4|3]
         self._w_halo = None
         self._idx_last = self._w_last = None
-        self.peak = 0.0
+        self._peak_dev = torch.zeros((), dtype=torch.float32, device=dev)
         self.samples_in = 0
         self._finished = False
 
@@ -48,33 +46,43 @@ class StreamRenderer:
         assert blk.dim() == 2 and blk.shape[0] == self.n_src, 'block must be [n_src, B]'
         B = blk.shape[1]
         assert B % self.K == 0 and B > 0, 'block length must be a positive multiple of the chunk size'
-        idx, w = sphere.interpolation_params_batch(elev, azim)
-        nb = B // self.K + 1
-        if idx.shape[:2] != (self.n_src, nb):
-            raise ValueError(f"elev/azim must have shape ({self.n_src}, {nb})")
         dev = self.tbl.device
+        # angles -> (indices, weights): on the device when the trajectory already lives there (long
+        # streams: no host work per block), else with the host's vectorised form; both are bit-identical
+        if isinstance(elev, torch.Tensor) and elev.is_cuda:
+            idx, w = sphere.interpolation_params_device(elev.to(torch.float64), torch.as_tensor(azim).to(dev, torch.float64))
+        else:
+            idx_h, w_h = sphere.interpolation_params_batch(elev, azim)
+            idx, w = torch.from_numpy(idx_h).to(dev), torch.from_numpy(w_h).to(dev)
+        nb = B // self.K + 1
+        if tuple(idx.shape[:2]) != (self.n_src, nb):
+            raise ValueError(f"elev/azim must have shape ({self.n_src}, {nb})")
         nh = self.halo // self.K
         if self._idx_halo is None:      # first block: the halo holds silence, any valid IR will do
-            self._idx_halo = np.repeat(idx[:, :1], nh, axis=1)
-            self._w_halo = np.repeat(w[:, :1], nh, axis=1)
-        idx_all = np.concatenate([self._idx_halo, idx], axis=1)        # boundaries t0-halo .. t0+B
-        w_all = np.concatenate([self._w_halo, w], axis=1)
+            self._idx_halo = idx[:, :1].repeat(1, nh, 1)
+            self._w_halo = w[:, :1].repeat(1, nh, 1)
+        idx_all = torch.cat([self._idx_halo, idx], dim=1)              # boundaries t0-halo .. t0+B
+        w_all = torch.cat([self._w_halo, w], dim=1)
         x = torch.empty((self.n_src, self.halo + B), dtype=torch.float32, device=dev)
         x[:, :self.halo] = self._x_halo
         x[:, self.halo:] = blk.to(device=dev, dtype=torch.float32)
-        idx_t = torch.from_numpy(np.ascontiguousarray(idx_all.reshape(-1, 4))).to(dev)
-        w_t = torch.from_numpy(np.ascontiguousarray(w_all.reshape(-1, 3))).to(dev)
-        y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_t, w_t, normalize="none")
+        y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_all.reshape(-1, 4).contiguous(),
+                                    w_all.reshape(-1, 3).contiguous(), normalize="none")
         out = y[:, self.halo:self.halo + B]
         # carry: last `halo` inputs and the parameters of their chunk boundaries (t0+B-halo .. t0+B-K)
         if self.halo:
             self._x_halo = x[:, B:B + self.halo].clone()
-            self._idx_halo = idx_all[:, nb - 1:nb - 1 + nh].copy()
-            self._w_halo = w_all[:, nb - 1:nb - 1 + nh].copy()
-        self._idx_last, self._w_last = idx[:, -1:].copy(), w[:, -1:].copy()     # boundary t0 + B
-        self.peak = max(self.peak, float(out.abs().max())) if out.numel() else self.peak
+            self._idx_halo = idx_all[:, nb - 1:nb - 1 + nh].clone()
+            self._w_halo = w_all[:, nb - 1:nb - 1 + nh].clone()
+        self._idx_last, self._w_last = idx[:, -1:].clone(), w[:, -1:].clone()   # boundary t0 + B
+        self._peak_dev = torch.maximum(self._peak_dev, out.abs().max()) if out.numel() else self._peak_dev
         self.samples_in += B
         return out.t()
+
+    @property
+    def peak(self):
+        """max |sample| emitted so far (reads back one float)."""
+        return float(self._peak_dev)
 
     def finish(self):
         """Emit the last L-1 samples (the tail the reference appends, apply_hrtf.py:410): render one
@@ -86,13 +94,12 @@ class StreamRenderer:
             raise RuntimeError("finish() before any block")
         L = self.tbl.L
         dev = self.tbl.device
-        idx_all = np.concatenate([self._idx_halo, self._idx_last, self._idx_last], axis=1)
-        w_all = np.concatenate([self._w_halo, self._w_last, self._w_last], axis=1)
+        idx_all = torch.cat([self._idx_halo, self._idx_last, self._idx_last], dim=1)
+        w_all = torch.cat([self._w_halo, self._w_last, self._w_last], dim=1)
         x = torch.cat([self._x_halo, torch.zeros((self.n_src, self.K), dtype=torch.float32, device=dev)], dim=1)
-        idx_t = torch.from_numpy(np.ascontiguousarray(idx_all.reshape(-1, 4))).to(dev)
-        w_t = torch.from_numpy(np.ascontiguousarray(w_all.reshape(-1, 3))).to(dev)
-        y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_t, w_t, normalize="none")
+        y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_all.reshape(-1, 4).contiguous(),
+                                    w_all.reshape(-1, 3).contiguous(), normalize="none")
         out = y[:, self.halo:self.halo + L - 1]
-        self.peak = max(self.peak, float(out.abs().max())) if out.numel() else self.peak
+        self._peak_dev = torch.maximum(self._peak_dev, out.abs().max()) if out.numel() else self._peak_dev
         self._finished = True
         return out.t()
