@@ -25,29 +25,30 @@
 //     h[m] = sum_k W_k * sample_k(m)
 // with the 16 weights W_k folded once per (query, ear) in binary64.
 #include "bas_internal.h"
+#include "bas_plan.h"
 #include <stdlib.h>
 #include <string.h>
 
 // ---------------------------------------------------------------------------
-// a1: [2][ndir][M] -> [2][ndir][U][L + 2]   (plane = [last sample][L samples][first sample])
+// a1: [2][ndir][M] -> [2][ndir][U][L + 4]   (plane = [last sample][L samples][first three samples])
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bas_pack_kernel(const float *__restrict__ irs, long rows,
                                                          int M, int U, int L,
                                                          float *__restrict__ packed) {
-    const int LP = L + 2;
+    const int LP = BAS_PLANE(L);
     long total = rows * (long)U * LP;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
         long row = i / ((long)U * LP);
         int j = (int)(i - row * U * LP);
-        int ph = j / LP, g = j - ph * LP;          // g = 0 and g = L + 1 are the guards
-        int idx = g == 0 ? L - 1 : (g == L + 1 ? 0 : g - 1);
+        int ph = j / LP, g = j - ph * LP;          // g = 0 and g > L are the guards
+        int idx = g == 0 ? L - 1 : (g > L ? (g - L - 1) % L : g - 1);
         packed[i] = irs[row * M + (long)idx * U + ph];
     }
 }
 
 extern "C" size_t bas_table_packed_floats(int ndir, int M, int U) {
     if (ndir <= 0 || U <= 0 || M <= 0 || M % U) return 0;
-    return (size_t)2 * ndir * U * (M / U + 2);
+    return (size_t)2 * ndir * U * BAS_PLANE(M / U);
 }
 
 extern "C" int bas_table_pack_f32(const float *irs, int ndir, int M, int U, float *packed,
@@ -56,7 +57,7 @@ extern "C" int bas_table_pack_f32(const float *irs, int ndir, int M, int U, floa
     BAS_REQUIRE(ndir > 0 && U > 0 && M > 0 && M % U == 0, BAS_E_SHAPE,
                 "bas_table_pack_f32: need ndir>0, U>0, M>0, M %% U == 0 (ndir=%d M=%d U=%d)", ndir, M, U);
     long rows = 2L * ndir;
-    long total = rows * U * (M / U + 2);
+    long total = rows * U * BAS_PLANE(M / U);
     int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(bas_pack_kernel, dim3(grid), dim3(256), 0, bas_stream(stream), irs, rows, M, U,
                        M / U, packed);
@@ -131,7 +132,7 @@ __device__ __forceinline__ float tab_read(const float *__restrict__ packed, int 
     }
     int idx = m + o;                 // m < L, o < L
     if (idx >= L) idx -= L;
-    return packed[row + ph * (L + 2) + 1 + idx];
+    return packed[row + ph * BAS_PLANE(L) + 1 + idx];
 }
 
 // R = S(B, al D) at the positions (c_p - j), j = 0..NR-1, relative to the lane's tap
@@ -162,8 +163,8 @@ __device__ __forceinline__ void ring_plan(RingPlan &rp, const double *__restrict
     float f1, f2;
     const int b1 = bas_split_shift_mod(-D, M, f1);                  // :86-87
     const int b2 = bas_split_shift_mod(s2, M, f2);                  // :98-99
-    rp.row_p = (e * ndir + p) * (M + 2 * U);   // plane stride L + 2
-    rp.row_q = (e * ndir + q) * (M + 2 * U);
+    rp.row_p = (e * ndir + p) * U * BAS_PLANE(L);
+    rp.row_q = (e * ndir + q) * U * BAS_PLANE(L);
     rp.c_p = bas_submod(c_out, b2, M);                              // B is read at (c_out - j) - b2 (-1)
     rp.c_q = bas_submod(rp.c_p, b1, M);
     rp.f1 = f1;
@@ -181,8 +182,6 @@ __device__ __forceinline__ void ring_plan(RingPlan &rp, const double *__restrict
 // wave-uniform and lives in SGPRs; per output tap a lane computes 4 wrapped offsets (one per set),
 // 16 loads off scalar bases and 16 FMAs with scalar weights.
 #define BAS_QB 16      // queries per workgroup
-
-#include "bas_plan.h"
 
 // plan kernel: one thread per (query, ear)
 __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__restrict__ diffs,
@@ -258,20 +257,38 @@ __global__ __launch_bounds__(256) void bas_interp2d_eval_kernel(const float *__r
                                                                   const EarPlanW *__restrict__ plans,
                                                                   long n_rows, int L, int U,
                                                                   float *__restrict__ H) {
+    // A wave evaluates TWO consecutive rows (= the two ears of a query): lanes 0-31 the first, lanes
+    // 32-63 the second, 4 adjacent taps per lane.  16-byte loads run the vector L1 at its full
+    // 64 B/clk; the 8-byte form of this kernel was bound by address processing at half that rate.
     const int lane = threadIdx.x & 63;
-    const long wave0 = rfl((int)(threadIdx.x >> 6)) + blockIdx.x * 4L;
-    const long n_waves = gridDim.x * 4L;
-    const int *pw = reinterpret_cast<const int *>(plans) + (lane & 31);
-    int word_next = wave0 < n_rows ? pw[wave0 * 32] : 0;
-    for (long row = wave0; row < n_rows; row += n_waves) {   // row = query * 2 + ear
+    const int half = lane >> 5;
+    const long pair0 = rfl((int)(threadIdx.x >> 6)) + blockIdx.x * 4L;
+    const long n_pairs = (n_rows + 1) >> 1;
+    const long stride = gridDim.x * 4L;
+    const int *pw = reinterpret_cast<const int *>(plans);
+    auto fetch = [&](long pr) {                               // one coalesced 256-byte load: both plans
+        long r = 2 * pr + half;
+        if (r > n_rows - 1) r = n_rows - 1;
+        return pw[r * 32 + (lane & 31)];
+    };
+    int word_next = pair0 < n_pairs ? fetch(pair0) : 0;
+    for (long pr = pair0; pr < n_pairs; pr += stride) {
         const int word = word_next;
-        const long nrow = row + n_waves;
-        word_next = pw[(nrow < n_rows ? nrow : row) * 32];
-        float *Hq = H + row * L;
-        for (int m = 2 * lane; m < L; m += 128) {            // a lane owns taps m, m + 1
-            const f32x2 acc = plan_eval_pair(packed, word, m, L, U);
-            if (m + 1 < L) *reinterpret_cast<f32x2_a4 *>(Hq + m) = acc;
-            else Hq[m] = acc.x;                              // odd L: the last tap stands alone
+        word_next = fetch(pr + stride < n_pairs ? pr + stride : pr);
+        const long row = 2 * pr + half;
+        float *Hq = H + (row < n_rows ? row : n_rows - 1) * L;
+        for (int m0 = 0; m0 < L; m0 += 128) {                // 32 lanes x 4 taps per sweep
+            const int m = m0 + 4 * (lane & 31);
+            const int m_c = m < L ? m : L - 1;               // idle lanes evaluate a valid tap and drop it
+            const f32x4 acc = plan_eval_quad(packed, word, half, m_c, L, U);
+            if (row < n_rows) {
+                if (m + 3 < L) *reinterpret_cast<f32x4_a4 *>(Hq + m) = acc;
+                else {
+                    if (m < L) Hq[m] = acc.x;
+                    if (m + 1 < L) Hq[m + 1] = acc.y;
+                    if (m + 2 < L) Hq[m + 2] = acc.z;
+                }
+            }
         }
     }
 }
@@ -285,7 +302,7 @@ extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, co
     BAS_REQUIRE(diffs && idx && w, BAS_E_NULL, "bas_interp2d_plan_f32: null pointer");
     BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
                 "bas_interp2d_plan_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
-    BAS_REQUIRE((long)2 * ndir * (L + 2) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_plan_f32: table too large");
+    BAS_REQUIRE((long)2 * ndir * BAS_PLANE(L) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_plan_f32: table too large");
     if (n == 0) return 0;
     BAS_REQUIRE(plans && plans_bytes >= bas_interp2d_workspace_bytes(n) &&
                     reinterpret_cast<uintptr_t>(plans) % 16 == 0,
@@ -303,7 +320,7 @@ extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const 
     BAS_REQUIRE(packed && diffs && idx && w && H, BAS_E_NULL, "bas_interp2d_f32: null pointer");
     BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
                 "bas_interp2d_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
-    BAS_REQUIRE((long)2 * ndir * (L + 2) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_f32: table too large");
+    BAS_REQUIRE((long)2 * ndir * BAS_PLANE(L) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_f32: table too large");
     if (n == 0) return 0;
     BAS_REQUIRE(ws && ws_bytes >= bas_interp2d_workspace_bytes(n) && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
                 BAS_E_WORKSPACE, "bas_interp2d_f32: 16-byte aligned workspace of %zu bytes needed, %zu given",
@@ -315,7 +332,7 @@ extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const 
                        w, n, ndir, L, U, plans);
     int rc = bas_check_launch("bas_interp2d_f32(plan)");
     if (rc) return rc;
-    long blocks = (rows + 3) / 4;
+    long blocks = ((rows + 1) / 2 + 3) / 4;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(bas_interp2d_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, plans, rows, L, U,
                        H);
@@ -357,7 +374,7 @@ extern "C" int bas_ring_interp_f32(const float *packed, const double *diffs, con
     BAS_REQUIRE(packed && diffs && pq && alpha && out, BAS_E_NULL, "bas_ring_interp_f32: null pointer");
     BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
                 "bas_ring_interp_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
-    BAS_REQUIRE((long)2 * ndir * (L + 2) * U < (1L << 31), BAS_E_SHAPE, "bas_ring_interp_f32: table too large");
+    BAS_REQUIRE((long)2 * ndir * BAS_PLANE(L) * U < (1L << 31), BAS_E_SHAPE, "bas_ring_interp_f32: table too large");
     if (n == 0) return 0;
     int step = return_upsampled ? 1 : U;
     int Mout = return_upsampled ? L * U : L;
