@@ -568,16 +568,17 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         int slot_b = slot_a + ((nslots + 1) >> 1);
         if (slot_b > nslots) slot_b = nslots;
         float hl[HD_HALFSLOTS + 1], hr[HD_HALFSLOTS + 1];
-        constexpr int HD_MAXEVAL = ((HD_MAXSLOTS + 1) * 2 + HD_NW - 1) / HD_NW;     // rows per wave
+        constexpr int HD_MAXEVAL = (HD_MAXSLOTS + 1 + HD_NW - 1) / HD_NW;           // chunk IRs per wave
         int pword[HD_MAXEVAL];
-        const int n_hrows = 2 * (nslots + 1);                // rows (slot, ear) of chunk IRs this pass needs
+        const int n_hslots = nslots + 1;                     // chunk IRs this pass needs
         if (FUSED) {
-            const int *pl = A.plans + ((long)s * (A.n_chunks + 1)) * 64 + (lane & 31);
+            // wave wv evaluates chunk IRs wv, wv+4, ..: lanes 0-31 the left ear, lanes 32-63 the right
+            const int *pl = A.plans + ((long)s * (A.n_chunks + 1)) * 64 + lane;    // 64 words per chunk: L|R plans
 #pragma unroll
             for (int i = 0; i < HD_MAXEVAL; ++i) {
-                int r = wv + HD_NW * i;                      // row = slot * 2 + ear
-                if (r > n_hrows - 1) r = n_hrows - 1;        // clamped: no branch around the load
-                pword[i] = pl[(long)(clampi(c0 + (r >> 1), 0, A.n_chunks) * 2 + (r & 1)) * 32];
+                int sl_i = wv + HD_NW * i;
+                if (sl_i > n_hslots - 1) sl_i = n_hslots - 1;    // clamped: no branch around the load
+                pword[i] = pl[(long)clampi(c0 + sl_i, 0, A.n_chunks) * 64];
             }
         } else {
             int k = seg0 + tap;
@@ -604,36 +605,27 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         }
         if (FUSED) {
             // interpolate_2d for the chunk IRs of this pass (apply_hrtf.py:219-279), taps seg0 .. seg0+Lseg:
-            // a lane owns two adjacent taps; h goes to (h0_L | h0_R) of its chunk slot
-            // Software-pipelined over rows: the loads of row i+1 are requested before row i is folded.
-            // Rows past the end repeat the last row; lanes past the end evaluate a clamped tap and
-            // simply do not store, so the loop body has no divergent branch.
-            const int m = seg0 + 2 * lane;
-            const int m_c = m < A.L - 1 ? m : (A.L > 1 ? A.L - 2 : 0);
-            const int n_iter = (n_hrows + HD_NW - 1) / HD_NW;
-            auto store_row = [&](int i, f32x2 h) {
-                int r = wv + HD_NW * i;
-                if (r > n_hrows - 1) r = n_hrows - 1;
-                if (m != m_c) {                              // only when the pair straddles or passes L
-                    h.x = (m == A.L - 1) ? h.y : 0.f;        // m = L-1: the clamped pair is (L-2, L-1)
-                    h.y = 0.f;                               // taps >= L read as zero
-                }
-                if (2 * lane < Lseg) {
-                    float *dst = hd + (r >> 1) * HD_SLOT + 8 * lane + (r & 1);
-                    dst[0] = h.x;
-                    dst[4] = h.y;
-                }
-            };
-            f32x2 va[16], vb[16];
-            plan_eval_issue(A.packed, pword[0], m_c, A.L, A.U, va);
+            // a lane owns four adjacent taps of one ear (16-byte table loads); h goes to (h0_L | h0_R)
+            const int half = lane >> 5;
+            const int mt = 4 * (lane & 31);                  // tap inside the segment
+            const int m = seg0 + mt;
+            const int m_c = m < A.L ? m : A.L - 1;
+            const int n_iter = (n_hslots + HD_NW - 1) / HD_NW;
 #pragma unroll
-            for (int i = 0; i < HD_MAXEVAL; i += 2) {
+            for (int i = 0; i < HD_MAXEVAL; ++i) {
                 if (i < n_iter) {                            // uniform
-                    if (i + 1 < n_iter) plan_eval_issue(A.packed, pword[i + 1 < HD_MAXEVAL ? i + 1 : i], m_c, A.L, A.U, vb);
-                    store_row(i, plan_eval_finish(pword[i], va));
-                    if (i + 1 < n_iter) {
-                        if (i + 2 < n_iter) plan_eval_issue(A.packed, pword[i + 2 < HD_MAXEVAL ? i + 2 : i], m_c, A.L, A.U, va);
-                        store_row(i + 1, plan_eval_finish(pword[i + 1 < HD_MAXEVAL ? i + 1 : i], vb));
+                    int sl_i = wv + HD_NW * i;
+                    if (sl_i > n_hslots - 1) sl_i = n_hslots - 1;
+                    f32x4 h = plan_eval_quad(A.packed, pword[i], half, m_c, A.L, A.U);
+                    if (m + 3 >= A.L) {                      // taps >= L read as zero
+                        if (m >= A.L) h.x = 0.f;
+                        if (m + 1 >= A.L) h.y = 0.f;
+                        if (m + 2 >= A.L) h.z = 0.f;
+                        h.w = 0.f;
+                    }
+                    if (mt < Lseg) {
+                        float *dst = hd + sl_i * HD_SLOT + 4 * mt + half;
+                        dst[0] = h.x; dst[4] = h.y; dst[8] = h.z; dst[12] = h.w;
                     }
                 }
             }
