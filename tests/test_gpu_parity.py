@@ -325,3 +325,25 @@ def test_device_params_kernel_is_bit_identical_to_host():
     idx_d, w_d = bas.sphere.interpolation_params_device(torch.from_numpy(e).cuda(), torch.from_numpy(z).cuda())
     assert np.array_equal(idx_d.cpu().numpy(), idx_h)
     assert np.array_equal(w_d.cpu().numpy(), w_h)
+
+
+def test_integration_md_stub_runs(tables):
+    """The ctypes stub printed in INTEGRATION.md is real code: run it (with this repo's sphere module
+    standing in for the reference's, same interface) on a golden case."""
+    import re
+    import sys
+    import types
+    from conftest import ROOT
+    import os
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n# hip_backend\.py.*?\n(.*?)```", text, re.S).group(1)
+    code = code.replace('"/path/to/binaural-audio-synthesis_amd/csrc/libbas_hip.so"', repr(bas._hip.LIB_PATH))
+    sys.modules.setdefault("sphere", bas.sphere)
+    mod = types.ModuleType("hip_backend")
+    exec(compile(code, "INTEGRATION.md:hip_backend", "exec"), mod.__dict__)
+    g = golden("render_spiral_512_32_128.npz")
+    meta = json.loads(str(g["meta"]))
+    dtab = mod.upload_table(tables["consistent"].truncated(128))
+    traj = bas.synth.trajectory(meta["traj"], fs=meta["fs"], **meta["traj_kw"])
+    got = mod.make_signal_move_2d(g["x"], 512, 32, traj, dtab)
+    assert got.shape == g["y"].shape and rel_err(got, g["y"]) <= REL
