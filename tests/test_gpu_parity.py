@@ -347,3 +347,41 @@ def test_integration_md_stub_runs(tables):
     traj = bas.synth.trajectory(meta["traj"], fs=meta["fs"], **meta["traj_kw"])
     got = mod.make_signal_move_2d(g["x"], 512, 32, traj, dtab)
     assert got.shape == g["y"].shape and rel_err(got, g["y"]) <= REL
+
+
+def test_hip_graph_capture_and_replay(dev_tables):
+    """include/bas.h promises stream-ordered, capturable entry points: capture interp2d + render + peak
+    rule into a hipGraph (torch.cuda.CUDAGraph), replay it on new inputs, compare with eager calls."""
+    import torch
+    h, d = dev_tables[("consistent", 128)]
+    n_src, n, k, s = 3, 8192, 512, 32
+    t = np.arange(0, n + 1, k, dtype=np.float64)
+    elev = np.stack([bas.synth.trajectory("spiral", length_s=n / 44100, turns=2.0, phase=i)(t)[0] for i in range(n_src)])
+    azim = np.stack([bas.synth.trajectory("spiral", length_s=n / 44100, turns=2.0, phase=i)(t)[1] for i in range(n_src)])
+    idx, w = bas.sphere.interpolation_params_batch(elev, azim)
+    idx_t = torch.from_numpy(idx.reshape(-1, 4)).cuda()
+    w_t = torch.from_numpy(w.reshape(-1, 3)).cuda()
+    x = torch.zeros((n_src, n), dtype=torch.float32, device="cuda")
+    y = torch.empty((2, n + 127), dtype=torch.float32, device="cuda")
+    lib = bas._hip.lib()
+    ws = torch.empty((lib.bas_render_workspace_bytes(n_src, n, k, s, 128),), dtype=torch.uint8, device="cuda")
+    wsp = torch.empty((lib.bas_interp2d_workspace_bytes(idx_t.shape[0]),), dtype=torch.uint8, device="cuda")
+
+    def run():
+        bas.apply_hrtf.render_params_device(x, k, s, d, idx_t, w_t, normalize="mix", out=y, ws=ws, ws_plans=wsp,
+                                            fused=False)
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):          # warm-up outside capture (allocator, lazy init)
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run()
+    for seed in (1, 2):
+        sig = torch.from_numpy(np.stack([bas.synth.integer_noise(seed * 10 + i, n, 0.4) for i in range(n_src)])).cuda()
+        x.copy_(sig)
+        graph.replay()
+        got = y.clone()
+        want = bas.render_sources(sig, k, s, elev, azim, d, fused=False).t()
+        assert torch.equal(got, want)
