@@ -441,34 +441,13 @@ __device__ __forceinline__ void hd_octet_fma(f32x2 (&acc)[32], const float (&xr)
         g[j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al, al}, f32x2{hv[j].x, hv[j].y});
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        constexpr int dummy = 0;
-        const int delta = 8 * I + j - 32 + dummy;
+        const int delta = 8 * I + j - 32;
 #pragma unroll
         for (int o = 0; o < 32; ++o) {
             const int a = o - delta;
             if (a >= 0 && a < 32) fma2(acc[o], xr[a], g[j]);
         }
     }
-}
-
-// Row step with every octet I0..7 live: straight-line code, the next octet's LDS words are requested
-// before the current octet's FMAs (two register buffers).
-template <int I0>
-__device__ __forceinline__ void hd_row_step_full(f32x2 (&acc)[32], const f32x4 *__restrict__ xrow,
-                                                  const float *__restrict__ hdrow, float al) {
-    float xr[32];
-    f32x4 ha[8], hb[8];
-    hd_load_xrow(xr, xrow);
-    hd_load_octet(ha, hdrow, I0);
-    if constexpr (I0 <= 0) { hd_load_octet(hb, hdrow, 1); hd_octet_fma<0>(acc, xr, ha, al); hd_load_octet(ha, hdrow, 2); hd_octet_fma<1>(acc, xr, hb, al);
-                             hd_load_octet(hb, hdrow, 3); hd_octet_fma<2>(acc, xr, ha, al); hd_load_octet(ha, hdrow, 4); hd_octet_fma<3>(acc, xr, hb, al); }
-    hd_load_octet(hb, hdrow, 5);
-    hd_octet_fma<4>(acc, xr, ha, al);
-    hd_load_octet(ha, hdrow, 6);
-    hd_octet_fma<5>(acc, xr, hb, al);
-    hd_load_octet(hb, hdrow, 7);
-    hd_octet_fma<6>(acc, xr, ha, al);
-    hd_octet_fma<7>(acc, xr, hb, al);
 }
 
 // Row step with a run-time set of live octets (segments shorter than 128 taps, last row).
