@@ -289,7 +289,7 @@ def render_sources(signals, chunksize, subchunksize, elev, azim, tbl, normalize=
 
 
 def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_function, irs_and_delaydiffs,
-                        verbose=False):
+                        verbose=False, vectorized=False):
     """Make `in_signal` sound as if its source moved along elev_azim_function
     (apply_hrtf.py:356-466): chunk IRs by interpolate_2d at t = 0, K, .., in_length,
     per-subchunk linear IR crossfade, direct FIR, overlap-add, float32, peak rule.
@@ -298,7 +298,10 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     device tensor (returns a device tensor of that shape).
     elev_azim_function(t_samples) -> (elev, azim) in radians; it is called with the
     same scalar arguments as the reference calls it, so grid-node decisions follow the
-    dtype it returns exactly as in the reference (sphere.py).
+    dtype it returns exactly as in the reference (sphere.py).  vectorized=True calls it
+    ONCE with the float64 array of all chunk times instead (it must broadcast) and uses
+    the float64 branch for every chunk: ~1000x less host time on long signals, identical
+    to the scalar path whenever the function returns np.float64 values.
     """
     import torch
     is_tensor = isinstance(in_signal, torch.Tensor)
@@ -310,12 +313,19 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     n = int(in_signal.shape[0])
     in_length, out_length = render_lengths(n, chunksize, tbl.L)
     times = range(0, in_length + 1, chunksize)                               # :429, :435
-    idx = np.empty((len(times), 4), dtype=np.int32)
-    w = np.empty((len(times), 3), dtype=np.float64)
-    for i, t in enumerate(times):
-        idx[i], w[i] = sphere.interpolation_params(*elev_azim_function(t))
-        if verbose:
-            print(' {:.1f}%           '.format(100 * t / max(in_length, 1)), end='\r')
+    if vectorized:
+        e, a = elev_azim_function(np.arange(0, in_length + 1, chunksize, dtype=np.float64))
+        e, a = np.broadcast_arrays(np.asarray(e, dtype=np.float64), np.asarray(a, dtype=np.float64))
+        if e.shape != (len(times),):
+            e, a = np.broadcast_to(e, (len(times),)), np.broadcast_to(a, (len(times),))
+        idx, w = sphere.interpolation_params_batch(e, a)
+    else:
+        idx = np.empty((len(times), 4), dtype=np.int32)
+        w = np.empty((len(times), 3), dtype=np.float64)
+        for i, t in enumerate(times):
+            idx[i], w[i] = sphere.interpolation_params(*elev_azim_function(t))
+            if verbose:
+                print(' {:.1f}%           '.format(100 * t / max(in_length, 1)), end='\r')
     x = torch.zeros((1, in_length), dtype=torch.float32, device=dev)         # :405-406
     src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
     x[0, :n] = src.to(device=dev, dtype=torch.float32)

@@ -385,3 +385,15 @@ def test_hip_graph_capture_and_replay(dev_tables):
         got = y.clone()
         want = bas.render_sources(sig, k, s, elev, azim, d, fused=False).t()
         assert torch.equal(got, want)
+
+
+def test_make_signal_move_2d_vectorized_trajectory(dev_tables):
+    g = golden("render_spiral_512_32_128.npz")
+    meta = json.loads(str(g["meta"]))
+    _, d = dev_tables[("consistent", 128)]
+    traj = bas.synth.trajectory(meta["traj"], fs=meta["fs"], **meta["traj_kw"])
+    a = bas.make_signal_move_2d(g["x"], 512, 32, traj, d)
+    b = bas.make_signal_move_2d(g["x"], 512, 32, traj, d, vectorized=True)
+    assert np.array_equal(a, b) and rel_err(b, g["y"]) <= REL
+    c = bas.make_signal_move_2d(g["x"], 512, 32, lambda t: (0.3, 1.0 + 0 * t), d, vectorized=True)   # broadcasting
+    assert c.shape == a.shape
