@@ -404,7 +404,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
 // (H_c, H_{c+1} - H_c) interleaved per tap as (h0_L, h0_R, d_L, d_R); the lane forms
 // g = h0 + al d (al = its row's crossfade weight) with one packed FMA per tap, 6 % on top of the FIR.
 // Nothing row-specific is staged, so a pass costs two barriers and a few dozen LDS stores; with ~71 KB
-// of LDS two 4-wave workgroups share a CU.  Needs S a power of two (>= 32) and at most 20 chunk
+// of LDS two 4-wave workgroups share a CU.  Needs S a power of two (>= 32; or 16 / 8 with K a multiple
+// of 32: a row then holds 2 / 4 subchunks, each with its own formed taps) and at most 20 chunk
 // slots per tile (K >= 448).
 #define HD_NW 4                               // waves per workgroup: one per SIMD, so the CU stays balanced
 #define HD_THREADS (64 * HD_NW)
@@ -431,28 +432,34 @@ __device__ __forceinline__ void hd_load_octet(f32x4 (&hv)[8], const float *__res
     for (int j = 0; j < 8; ++j) hv[j] = *reinterpret_cast<const f32x4 *>(hdrow + (8 * i + j) * 4);
 }
 
-// one octet of taps (delta = 8 i + j - 32 = output index - input index) against the whole input row
-template <int I>
+// one octet of taps (delta = 8 i + j - 32 = output index - input index) against the whole input row.
+// NSUB > 1: the subchunk is shorter than a row (S = 32 / NSUB), so the row's 32 inputs fall into NSUB
+// groups with their own crossfade weight al[u]; each group gets its own formed taps.
+template <int I, int NSUB>
 __device__ __forceinline__ void hd_octet_fma(f32x2 (&acc)[32], const float (&xr)[32], const f32x4 (&hv)[8],
-                                              float al) {
-    f32x2 g[8];
+                                              const float (&al)[NSUB]) {
+    f32x2 g[NSUB][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-        g[j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al, al}, f32x2{hv[j].x, hv[j].y});
+    for (int u = 0; u < NSUB; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            g[u][j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al[u], al[u]},
+                                                f32x2{hv[j].x, hv[j].y});
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int delta = 8 * I + j - 32;
 #pragma unroll
         for (int o = 0; o < 32; ++o) {
             const int a = o - delta;
-            if (a >= 0 && a < 32) fma2(acc[o], xr[a], g[j]);
+            if (a >= 0 && a < 32) fma2(acc[o], xr[a], g[a / (32 / NSUB)][j]);
         }
     }
 }
 
 // Row step with a run-time set of live octets (segments shorter than 128 taps, last row).
+template <int NSUB>
 __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4 *__restrict__ xrow,
-                                                    const float *__restrict__ hdrow, float al,
+                                                    const float *__restrict__ hdrow, const float (&al)[NSUB],
                                                     unsigned live_mask) {
     float xr[32];
     hd_load_xrow(xr, xrow);
@@ -460,14 +467,14 @@ __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4
 #define HD_MASKED_OCTET(I)                          \
     if (live_mask & (1u << I)) {                    \
         hd_load_octet(hv, hdrow, I);                \
-        hd_octet_fma<I>(acc, xr, hv, al);           \
+        hd_octet_fma<I, NSUB>(acc, xr, hv, al);     \
     }
     HD_MASKED_OCTET(0) HD_MASKED_OCTET(1) HD_MASKED_OCTET(2) HD_MASKED_OCTET(3)
     HD_MASKED_OCTET(4) HD_MASKED_OCTET(5) HD_MASKED_OCTET(6) HD_MASKED_OCTET(7)
 #undef HD_MASKED_OCTET
 }
 
-template <bool FUSED>
+template <bool FUSED, int NSUB>
 __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs A, int nslots) {
     extern __shared__ f32x4 lds4[];
     f32x4 *xs4 = lds4;                                       // [8][HD_XR] float4
@@ -645,8 +652,13 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             }
             return mk;
         };
-        auto step_setup = [&](int rp, float &al, const float *&hdrow) {
-            al = (float)(m_in - (m_in & (A.S - 1))) * invK;                  // S is a power of two here
+        auto step_setup = [&](int rp, float (&al)[NSUB], const float *&hdrow) {
+            if (NSUB == 1) {
+                al[0] = (float)(m_in - (m_in & (A.S - 1))) * invK;           // S is a power of two here
+            } else {
+#pragma unroll
+                for (int u = 0; u < NSUB; ++u) al[u] = (float)(m_in + u * (32 / NSUB)) * invK;   // S = 32 / NSUB
+            }
             hdrow = hd + sl * HD_SLOT + (32 * rp - 32) * 4;
         };
         auto step_done = [&]() {
@@ -671,10 +683,10 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                 if ((t & 1u) ^ prio_flip) __builtin_amdgcn_s_setprio(2);
                 else __builtin_amdgcn_s_setprio(0);
             }
-            float al;
+            float al[NSUB];
             const float *hdrow;
             step_setup(rp, al, hdrow);
-            hd_row_step_masked(acc, xrow, hdrow, al, mask_of(rp));
+            hd_row_step_masked<NSUB>(acc, xrow, hdrow, al, mask_of(rp));
             step_done();
         }
 #ifdef BAS_STAMPS
@@ -853,12 +865,14 @@ struct RenderPlan {
 static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool aligned) {
     RenderPlan p = {};
     p.kind = KIND_GENERIC;
-    if (!(aligned && n_src > 0 && T_in > 0 && S % 32 == 0)) return p;
     const bool s_pow2 = (S & (S - 1)) == 0;
+    const bool hd_small_s = s_pow2 && (S == 16 || S == 8) && K % 32 == 0;     // rows of 32 hold 2 / 4 subchunks
+    if (!(aligned && n_src > 0 && T_in > 0 && (S % 32 == 0 || hd_small_s))) return p;
     const int hd_slots = (K - 32 + 32 * (HD_ROWS - 1)) / K + 1;
     const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
     int kind = (s_pow2 && hd_slots <= HD_MAXSLOTS) ? KIND_HD : KIND_ROWS32;
     if (force && !strcmp(force, "rows32")) kind = KIND_ROWS32;
+    if (kind == KIND_ROWS32 && S % 32 != 0) return p;        // small subchunks: hd kernel or nothing
     if (force && !strcmp(force, "generic")) return p;
     if (kind == KIND_ROWS32 && L % 2 != 0) return p;         // rows32 loads tap pairs
     long wg_per_cu;
@@ -966,16 +980,19 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     A.slab = reinterpret_cast<float *>(ws);
     { const char *d = getenv("BAS_DEBUG_FLAGS"); A.dbg = d ? atoi(d) : 0; }
     A.packed = packed; A.plans = reinterpret_cast<const int *>(plans); A.U = U;
-    const void *fn = p.kind == KIND_HD ? (fused ? reinterpret_cast<const void *>(bas_render_hd_kernel<true>)
-                                                : reinterpret_cast<const void *>(bas_render_hd_kernel<false>))
+    const int nsub = S >= 32 ? 1 : 32 / S;
+    BAS_REQUIRE(!fused || nsub == 1, BAS_E_SHAPE, "bas_render_mix_fused_f32: subchunks shorter than 32 are not fused");
+    typedef void (*hd_fn)(RenderArgs, int);
+    hd_fn hdk = fused ? bas_render_hd_kernel<true, 1>
+                      : (nsub == 1 ? bas_render_hd_kernel<false, 1>
+                                   : (nsub == 2 ? bas_render_hd_kernel<false, 2> : bas_render_hd_kernel<false, 4>));
+    const void *fn = p.kind == KIND_HD ? reinterpret_cast<const void *>(hdk)
                                         : reinterpret_cast<const void *>(bas_render_rows32_kernel);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
-    if (p.kind == KIND_HD && fused)
-        hipLaunchKernelGGL(bas_render_hd_kernel<true>, dim3(p.n_wg), dim3(HD_THREADS), p.lds_bytes, st, A, p.hd_slots);
-    else if (p.kind == KIND_HD)
-        hipLaunchKernelGGL(bas_render_hd_kernel<false>, dim3(p.n_wg), dim3(HD_THREADS), p.lds_bytes, st, A, p.hd_slots);
+    if (p.kind == KIND_HD)
+        hipLaunchKernelGGL(hdk, dim3(p.n_wg), dim3(HD_THREADS), p.lds_bytes, st, A, p.hd_slots);
     else
         hipLaunchKernelGGL(bas_render_rows32_kernel, dim3(p.n_wg), dim3(RT_THREADS), p.lds_bytes, st, A);
     if (ev_end) (void)hipEventRecord(ev_end, st);
@@ -1004,7 +1021,7 @@ extern "C" int bas_render_mix_profiled_f32(const float *x, long x_stride, const 
 
 extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L) {
     if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return 0;
-    return plan_render(n_src, T_in, K, S, L, true).kind == KIND_HD ? 1 : 0;
+    return (S >= 32 && plan_render(n_src, T_in, K, S, L, true).kind == KIND_HD) ? 1 : 0;
 }
 
 extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed, const void *plans,

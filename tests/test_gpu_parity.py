@@ -169,7 +169,10 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
                                                    ("generic", 2, 3000, 512, 32, 128),
                                                    ("", 3, 5000, 128, 32, 128),          # K < 448: rows32 by itself
                                                    ("", 3, 5000, 1024, 256, 128),        # hd kernel, S > 32
-                                                   ("", 2, 4000, 512, 32, 99)])          # odd L
+                                                   ("", 2, 4000, 512, 32, 99),           # odd L
+                                                   ("", 3, 9000, 512, 16, 128),          # hd kernel, 2 subchunks per row
+                                                   ("", 3, 9000, 512, 8, 100),           # hd kernel, 4 subchunks per row
+                                                   ("", 2, 3000, 464, 16, 128)])         # K % 32 != 0: generic
 def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_src, n, k, s, l):
     """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL."""
     if force:
@@ -211,6 +214,9 @@ def test_kernel_selection():
     assert lib.bas_render_kernel_name(256, 441344, 512, 32, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 128, 32, 128) == b"bas_render_rows32_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 128, 16, 128) == b"bas_render_generic_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 512, 16, 128) == b"bas_render_hd_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 512, 8, 128) == b"bas_render_hd_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 464, 16, 128) == b"bas_render_generic_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 480, 96, 128) == b"bas_render_rows32_kernel"   # S not a power of two
 
 
