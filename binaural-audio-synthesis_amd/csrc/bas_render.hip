@@ -762,15 +762,16 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__res
     const long n4 = (T_out + 3) / 4;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
         const long n = i * 4;
-        const long tile = n / tile_len;
-        const int off = (int)(n - tile * tile_len);
-        const long ulo = tile * n_src, uhi = ulo + n_src - 1;
-        const int wlo = (int)(ulo / units_per_wg);
-        int whi = (int)(uhi / units_per_wg);
+        // (tiles * n_src = units_total < 2^31 is checked by the launcher: 32-bit divisions suffice)
+        const unsigned tile = (unsigned)(n / tile_len);
+        const int off = (int)(n - (long)tile * tile_len);
+        const unsigned ulo = tile * (unsigned)n_src, uhi = ulo + n_src - 1;
+        const int wlo = (int)(ulo / (unsigned)units_per_wg);
+        int whi = (int)(uhi / (unsigned)units_per_wg);
         if (whi > n_wg - 1) whi = n_wg - 1;
         f32x4 sl = f32x4{0.f, 0.f, 0.f, 0.f}, sr = sl;
         for (int w = wlo; w <= whi; ++w) {
-            const long first_tile = ((long)w * units_per_wg) / n_src;
+            const unsigned first_tile = ((unsigned)w * (unsigned)units_per_wg) / (unsigned)n_src;
             const float *p = slab + (((long)w * parts_per_wg + (tile - first_tile)) * 2) * tile_len + off;
             sl += *reinterpret_cast<const f32x4 *>(p);
             sr += *reinterpret_cast<const f32x4 *>(p + tile_len);
@@ -971,6 +972,8 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
         if (ev_end) (void)hipEventRecord(ev_end, st);
         return bas_check_launch("bas_render_mix_f32(generic)");
     }
+    BAS_REQUIRE(p.units_total < (1L << 31) - 65536, BAS_E_SHAPE,
+                "bas_render_mix_f32: %ld (tile, source) work units exceed 2^31: render in blocks", p.units_total);
     BAS_REQUIRE(ws && ws_bytes >= p.slab_bytes, BAS_E_WORKSPACE,
                 "bas_render_mix_f32: workspace of %zu bytes needed, %zu given", p.slab_bytes, ws_bytes);
     RenderArgs A;
