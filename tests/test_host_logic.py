@@ -103,3 +103,25 @@ def test_no_product_module_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.replace("no CPU fallback", ""), f
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No CPU fallback: without the built .so every compute entry point raises."""
+    hip = bas._hip
+    monkeypatch.setattr(hip, "_lib", None)
+    monkeypatch.setattr(hip, "LIB_PATH", "/nonexistent/libbas_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback|is missing"):
+        hip.lib()
+    with pytest.raises(RuntimeError):
+        hip.call("bas_version")
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    t = bas.synth.make_table("consistent", 0).truncated(16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        bas.irs_and_delaydiffs(t.upsampling, t.diffs_left, t.diffs_right, t.irs_left, t.irs_right)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        bas.delay_signal_float(np.zeros(8), 0.5)
