@@ -403,3 +403,23 @@ def test_make_signal_move_2d_vectorized_trajectory(dev_tables):
     assert np.array_equal(a, b) and rel_err(b, g["y"]) <= REL
     c = bas.make_signal_move_2d(g["x"], 512, 32, lambda t: (0.3, 1.0 + 0 * t), d, vectorized=True)   # broadcasting
     assert c.shape == a.shape
+
+
+@pytest.mark.parametrize("l,k,s", [(1, 512, 32), (2, 512, 32), (7, 512, 512), (8, 64, 32), (130, 480, 96), (33, 1024, 1024),
+                                   (128, 2048, 128), (5, 32, 32), (64, 960, 64), (17, 512, 16), (40, 544, 8), (128, 96, 32)])
+def test_odd_shapes_adversarial_table(tables, l, k, s):
+    """Odd IR lengths / chunk sizes, random (not smooth) trajectories, the adversarial table
+    (random antisymmetric delays up to +-40 samples): every kernel choice stays within REL."""
+    rng = np.random.default_rng(l * 100003 + k * 17 + s)
+    h = tables["adversarial"].truncated(l)
+    d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    n_src, n = int(rng.integers(1, 5)), int(rng.integers(1, 4 * k + 3000))
+    sigs = np.stack([bas.synth.integer_noise(int(rng.integers(1e6)), n, 0.05) for _ in range(n_src)])
+    in_length, _ = orc.render_lengths(n, k, l)
+    t = np.arange(0, in_length + 1, k, dtype=np.float64)
+    elev = rng.uniform(-1.0, 1.7, size=(n_src, t.size))
+    azim = rng.uniform(-7, 7, size=(n_src, t.size))
+    irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(t.size)]) for i in range(n_src)]
+    want = orc.render_mix(sigs, k, s, irs, normalize=False)
+    got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none").cpu().numpy()
+    assert got.shape == want.shape and rel_err(got, want) <= REL
