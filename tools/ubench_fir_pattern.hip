@@ -1,0 +1,63 @@
+// Micro-benchmark: the FIR's register pattern without any memory traffic:
+// acc[o] (float2) += x[a] (scalar, op_sel broadcast) * g[j] (float2), a = o - delta, as in hd_octet_fma.
+// Shows what the v_pk_fma_f32 stream alone sustains at 1/2/4 waves per SIMD with compiler-allocated registers.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int I>
+__device__ __forceinline__ void octet(f32x2 (&acc)[32], const float (&xr)[32], const f32x2 (&g)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int delta = 8 * I + j - 32;
+#pragma unroll
+        for (int o = 0; o < 32; ++o) {
+            const int a = o - delta;
+            if (a >= 0 && a < 32) acc[o] = __builtin_elementwise_fma(g[j], f32x2{xr[a], xr[a]}, acc[o]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k(float *out, const float *in, int iters) {
+    f32x2 acc[32];
+    float xr[32];
+    f32x2 g[8];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { acc[i] = f32x2{0.f, 0.f}; xr[i] = in[threadIdx.x + i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = f32x2{in[i], in[i + 8]};
+    for (int it = 0; it < iters; ++it) {
+        octet<0>(acc, xr, g); octet<1>(acc, xr, g); octet<2>(acc, xr, g); octet<3>(acc, xr, g);
+        octet<4>(acc, xr, g); octet<5>(acc, xr, g); octet<6>(acc, xr, g); octet<7>(acc, xr, g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(g[i]));      // keep the loop from being folded
+    }
+    float r = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r += acc[i].x + acc[i].y;
+    out[blockIdx.x * 256 + threadIdx.x] = r;
+}
+
+int main() {
+    float *out, *in;
+    (void)hipMalloc(&out, 1 << 24);
+    (void)hipMalloc(&in, 4096);
+    (void)hipMemset(in, 0, 4096);
+    const int iters = 400;
+    for (int wps = 1; wps <= 2; ++wps) {
+        int blocks = 256 * wps;
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, in, iters);
+        (void)hipEventRecord(e0);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(256), 0, 0, out, in, iters);
+        (void)hipEventRecord(e1);
+        (void)hipDeviceSynchronize();
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        double pk = 1024.0 * iters;                                      // packed FMAs per lane
+        double flops = pk * 4 * 64 * 4 * blocks;
+        printf("waves/SIMD=%d: %.3f ms, %.1f TFLOP/s (%.2f cycles per v_pk_fma_f32 per SIMD at 2.0 GHz)\n", wps, ms,
+               flops / (ms * 1e-3) / 1e12, (ms * 1e-3 * 2.0e9) / (pk * wps));
+    }
+    return 0;
+}
