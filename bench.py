@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--sources", type=int, default=256, help="sources per GPU")
+    ap.add_argument("--sources", type=int, default=256, help="sources per GPU (weak) / in the whole scene (strong)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every GPU renders --sources sources; strong: BASELINE config 4 read "
+                         "literally, ONE --sources-source scene sharded over the GPUs")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--subchunk", type=int, default=32)
@@ -213,6 +216,8 @@ def main():
 
     n = int(round(args.seconds * FS))
     k, s, l, n_src = args.chunk, args.subchunk, args.taps, args.sources
+    if args.scaling == "strong":                             # one scene, sources split over the ranks
+        n_src = len(bas.distributed.shard_sources(args.sources, world, rank))
     in_length = -(-n // k) * k
     t_out = in_length + l - 1
     n_q = in_length // k + 1
@@ -222,14 +227,15 @@ def main():
     tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left,
                                  host.irs_right, device=dev)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)
-    total_src = n_src * world
+    total_src = n_src * world if args.scaling == "weak" else args.sources
+    first_src = rank * n_src if args.scaling == "weak" else bas.distributed.shard_sources(args.sources, world, rank).start
     x = torch.zeros((n_src, in_length), dtype=torch.float32, device=dev)
     x[:, :n] = (torch.rand((n_src, n), generator=gen, device=dev) * 2 - 1) * (1.0 / total_src)
     tq = np.arange(0, in_length + 1, k, dtype=np.float64)
     elev = np.empty((n_src, n_q))
     azim = np.empty((n_src, n_q))
     for i in range(n_src):
-        elev[i], azim[i] = source_trajectory(bas.synth, rank * n_src + i, total_src, n)(tq)
+        elev[i], azim[i] = source_trajectory(bas.synth, first_src + i, total_src, n)(tq)
     idx_h, w_h = bas.sphere.interpolation_params_batch(elev, azim)
     idx = torch.from_numpy(idx_h.reshape(-1, 4)).to(dev)
     w = torch.from_numpy(w_h.reshape(-1, 3)).to(dev)
@@ -291,7 +297,9 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * t_out * args.steps / elapsed
+        # weak: 256-source-scene equivalents per second; strong: the one scene's stereo samples per second
+        scenes = world if args.scaling == "weak" else 1
+        value = scenes * t_out * args.steps / elapsed
         # algorithmic bytes of one FIR launch: inputs once, stereo mix once,
         # table once, 28 B of parameters per chunk IR
         m_cols = l * host.upsampling
@@ -307,15 +315,15 @@ def main():
         out = {
             "metric": "stereo samples/sec, 256 concurrent moving sources per GPU @44.1kHz (x real-time in x_realtime)",
             "value": value, "unit": "stereo samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE config 4 per GPU: {n_src} moving sources x {args.seconds:g} s @ {FS} Hz mono "
                                    f"-> 1 stereo mix; chunk {k}, subchunk {s}, {l}-tap HRIRs (U=8, 187 directions), "
                                    f"spiral/askew-circle trajectories; scene = {total_src} sources on {world} GPU(s)",
                        "sources_per_gpu": n_src, "samples_per_source": n, "chunk": k, "subchunk": s, "taps": l,
                        "out_samples": t_out, "parallelism": f"sources sharded over {world} GPU(s), 1 gather"},
-            "x_realtime": (n / FS) * world / (elapsed / args.steps),
-            "source_samples_per_s": world * n_src * in_length * args.steps / elapsed,
+            "x_realtime": (n / FS) * scenes / (elapsed / args.steps),
+            "source_samples_per_s": total_src * in_length * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": algo_bytes / fir_avg_s / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / fir_avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": _hip.lib().bas_render_kernel_name(n_src, in_length, k, s, l).decode(), "kernel_ms": fir_avg_s * 1e3,

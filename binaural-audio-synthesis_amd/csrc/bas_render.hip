@@ -672,17 +672,17 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
 #ifdef BAS_STAMPS
         const unsigned long long tf0 = __builtin_amdgcn_s_memrealtime();
 #endif
+        // Fair time slicing between the two workgroups of a CU.  The SIMD arbiter serves the older
+        // wave first, so without this the first-dispatched workgroup runs at nearly full speed,
+        // finishes ~35 % early and leaves the CU with one wave per SIMD.  Priority alternates every
+        // 2^slice_shift ticks of the 100 MHz clock, in opposite phase for the two halves of the grid
+        // (blocks b and b + grid/2 share a CU under the observed dispatch order; speed only).
+        if (prio_slice) {
+            const unsigned t = (unsigned)(__builtin_amdgcn_s_memrealtime() >> prio_slice);
+            if ((t & 1u) ^ prio_flip) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         for (int rp = 0; rp <= halo; ++rp) {
-            // Fair time slicing between the two workgroups of a CU.  The SIMD arbiter serves the older
-            // wave first, so without this the first-dispatched workgroup runs at nearly full speed,
-            // finishes ~35 % early and leaves the CU with one wave per SIMD.  Priority alternates every
-            // 2^slice_shift ticks of the 100 MHz clock, in opposite phase for the two halves of the grid
-            // (blocks b and b + grid/2 share a CU under the observed dispatch order; speed only).
-            if (prio_slice) {
-                const unsigned t = (unsigned)(__builtin_amdgcn_s_memrealtime() >> prio_slice);
-                if ((t & 1u) ^ prio_flip) __builtin_amdgcn_s_setprio(2);
-                else __builtin_amdgcn_s_setprio(0);
-            }
             float al[NSUB];
             const float *hdrow;
             step_setup(rp, al, hdrow);
