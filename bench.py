@@ -330,7 +330,9 @@ def main():
                          "algorithmic_bytes": algo_bytes},
             "valu": {"achieved": algo_flops / fir_avg_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": algo_flops / fir_avg_s / 1e12 / FP32_VALU_PEAK_TF,
-                     "note": "the FIR is 128 flop/B: fp32-VALU bound, HBM fraction tops out near 15 %"},
+                     "note": "the FIR is 128 flop/B: fp32-VALU bound, HBM fraction tops out near 15 %; peak is nominal "
+                             "(2.4 GHz) - a bare v_pk_fma_f32 stream on random operands sustains 97 TFLOP/s here "
+                             "(power-limited clock, tools/ubench_fir_pattern.hip, DESIGN.md 4)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, n, t_out)

@@ -42,7 +42,12 @@ int main() {
     float *out, *in;
     (void)hipMalloc(&out, 1 << 24);
     (void)hipMalloc(&in, 4096);
-    (void)hipMemset(in, 0, 4096);
+    {   // random operands: zero-filled inputs let the chip clock ~15 % higher (DVFS) and overstate the ceiling
+        static float hbuf[2048];
+        unsigned s = 12345u;
+        for (int i = 0; i < 2048; ++i) { s = s * 1664525u + 1013904223u; hbuf[i] = ((s >> 8) * (1.0f / 8388608.0f) - 1.0f) * 0.01f; }
+        (void)hipMemcpy(in, hbuf, 4096, hipMemcpyHostToDevice);
+    }
     const int iters = 400;
     for (int wps = 1; wps <= 2; ++wps) {
         int blocks = 256 * wps;
