@@ -145,46 +145,79 @@ class HipEvents:
 def stream_mode(args):
     """BASELINE config 5 (1024 sources, 48 kHz, hours of audio) in miniature: `steps` blocks of `block`
     samples through StreamRenderer; nothing but one block of inputs, chunk IRs and outputs is ever resident,
-    and the trajectory -> parameter step runs on the device.  One JSON line, not the contract's metric."""
+    and the trajectory -> parameter step runs on the device.  With --gpus N (torch.distributed.run) the
+    1024 sources are sharded over the ranks and every block ends in one gather of the partial stereo block
+    (distributed.ShardedStreamRenderer).  One JSON line, not the contract's metric."""
     import math
     import torch
+    import torch.distributed as dist
     import binaural_audio_synthesis_amd as bas
-    dev = torch.device("cuda", 0)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if os.environ.get("BAS_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    n_src, k, s, l, fs, B = args.sources, args.chunk, args.subchunk, args.taps, args.fs, args.block
+    if world > 1:
+        backend = os.environ.get("BAS_BENCH_BACKEND", "nccl")
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    n_total, k, s, l, fs, B = args.sources, args.chunk, args.subchunk, args.taps, args.fs, args.block
     host = bas.synth.make_table("consistent", 0).truncated(l)
     tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left, host.irs_right,
                                  device=dev)
-    st = bas.StreamRenderer(tbl, n_src, k, s)
-    src = torch.arange(n_src, dtype=torch.float64, device=dev)[:, None]
-    phase = 2 * math.pi * src / n_src
+    st = bas.distributed.ShardedStreamRenderer(tbl, n_total, k, s)
+    n_src = len(st.sources)
+    src = torch.arange(st.sources.start, st.sources.stop, dtype=torch.float64, device=dev)[:, None]
+    phase = 2 * math.pi * src / n_total
     period = (2.0 + (src % 256) / 64.0) * fs
-    gen = torch.Generator(device=dev).manual_seed(5)
+    gen = torch.Generator(device=dev).manual_seed(5 + rank)
+    gloo = world > 1 and dist.get_backend() == "gloo"
 
     def block(i):
         t = (torch.arange(B // k + 1, dtype=torch.float64, device=dev)[None, :] * k + i * B)
         elev = (math.pi / 4) * torch.cos(2 * math.pi * t / period + phase)          # askew circles, per-source period
         azim = 2 * math.pi * t / period + phase
-        x = (torch.rand((n_src, B), generator=gen, device=dev) * 2 - 1) * (1.0 / n_src)
+        x = (torch.rand((n_src, B), generator=gen, device=dev) * 2 - 1) * (1.0 / n_total)
         return x, elev, azim
 
+    def step(i):
+        if not gloo:
+            return st.process(*block(i))
+        y = st.local.process(*block(i))                              # rehearsal: stage the gather through the host
+        res = bas.distributed.gather_mix(y.t().cpu(), normalize="none", return_peak=True,
+                                         mix_fn=lambda parts: (parts.sum(0), parts.sum(0).abs().max().reshape(1)))
+        return None if res is None else res[0]
+
     for i in range(args.warmup):
-        st.process(*block(i))
+        step(i)
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
-        y = st.process(*block(i))
+        y = step(i)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if gloo else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
     audio_s = args.steps * B / fs
-    print(json.dumps({"metric": "streaming render, x real-time", "value": audio_s / el, "unit": "x real-time",
-                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-                      "higher_is_better": True, "dtype": "f32", "data": "synthetic (generated on device, included in time)",
-                      "config": {"workload": f"BASELINE config 5 shape: {n_src} sources @ {fs} Hz streamed in blocks of {B} "
-                                             f"samples, chunk {k}, subchunk {s}, {l} taps", "block": B},
-                      "source_samples_per_s": n_src * B * args.steps / el,
-                      "hour_of_audio_seconds": 3600.0 / (audio_s / el), "peak": st.peak,
-                      "out_block_shape": list(y.shape)}), flush=True)
+    if rank == 0:
+        print(json.dumps({"metric": "streaming render, x real-time", "value": audio_s / el, "unit": "x real-time",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "strong", "dtype": "f32",
+                          "data": "synthetic (generated on device, included in time)",
+                          "config": {"workload": f"BASELINE config 5 shape: {n_total} sources @ {fs} Hz streamed in blocks of {B} "
+                                                 f"samples, chunk {k}, subchunk {s}, {l} taps; sources sharded over {world} GPU(s), "
+                                                 f"one gather per block", "block": B},
+                          "source_samples_per_s": n_total * B * args.steps / el,
+                          "hour_of_audio_seconds": 3600.0 / (audio_s / el), "peak": None if gloo else st.peak,
+                          "out_block_shape": list(y.shape)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():

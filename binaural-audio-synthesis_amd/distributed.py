@@ -37,23 +37,23 @@ def _hip_scale_by_peak(y, peak):
     return y
 
 
-def gather_mix(partial, group=None, dst=0, mix_fn=None, scale_fn=None, normalize="mix"):
+def gather_mix(partial, group=None, dst=0, mix_fn=None, scale_fn=None, normalize="mix", return_peak=False):
     """Combine per-rank partial mixes [2, T_out] on rank `dst`.
 
-    Returns the final (T_out, 2) mix on rank dst and None elsewhere.  mix_fn / scale_fn
-    default to the HIP library; CPU tests inject numpy stand-ins to exercise the
-    collective under gloo.
+    Returns the final (T_out, 2) mix on rank dst and None elsewhere (with return_peak: the pair
+    (mix, peak tensor [1] of the un-normalised mix)).  mix_fn / scale_fn default to the HIP
+    library; CPU tests inject numpy stand-ins to exercise the collective under gloo.
     """
     import torch
     import torch.distributed as dist
     mix_fn = mix_fn or _hip_mix_partials
     scale_fn = scale_fn or _hip_scale_by_peak
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    partial = partial.contiguous()                             # mix_fn and the collective assume dense [2, T]
     if world == 1:
         y, peak = mix_fn(partial.unsqueeze(0))
     else:
         rank = dist.get_rank(group)
-        partial = partial.contiguous()
         if rank == dst:
             parts = torch.empty((world,) + tuple(partial.shape), dtype=partial.dtype, device=partial.device)
             dist.gather(partial, gather_list=list(parts.unbind(0)), dst=dst, group=group)
@@ -63,7 +63,7 @@ def gather_mix(partial, group=None, dst=0, mix_fn=None, scale_fn=None, normalize
             return None
     if normalize == "mix":
         y = scale_fn(y, peak)
-    return y.t()
+    return (y.t(), peak) if return_peak else y.t()
 
 
 def render_sources_sharded(signals, chunksize, subchunksize, elev, azim, tbl, group=None, dst=0,
@@ -142,3 +142,51 @@ def render_time_sharded(signals, chunksize, subchunksize, elev, azim, tbl, ir_le
         peak = full.abs().max().reshape(1)
         full = scale_fn(full, peak)
     return full
+
+
+# --------------------------------------------------------------------------
+# streaming (BASELINE config 5): sources sharded, one gather per block
+# --------------------------------------------------------------------------
+class ShardedStreamRenderer:
+    """StreamRenderer over the ranks of a process group: rank g streams its own block of sources
+    (`sources`, from shard_sources) with its own carried state; each process()/finish() ends in one
+    gather of the [2, B] partial block to rank dst and the fixed-order sum there.  Audio is returned
+    un-normalised on rank dst (None elsewhere); `peak` is the running max |sample| of the MIX.
+
+    stream_factory(tbl, n_local, K, S) defaults to StreamRenderer; mix_fn as in gather_mix (CPU tests
+    inject stand-ins for both)."""
+
+    def __init__(self, tbl, n_src_total, chunksize, subchunksize, group=None, dst=0, stream_factory=None,
+                 mix_fn=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if n_src_total < world:
+            raise ValueError(f"{n_src_total} sources cannot be sharded over {world} ranks")
+        self.sources = shard_sources(n_src_total, world, rank)
+        if stream_factory is None:
+            from .stream import StreamRenderer
+            stream_factory = StreamRenderer
+        self.local = stream_factory(tbl, len(self.sources), chunksize, subchunksize)
+        self.group, self.dst, self.mix_fn = group, dst, mix_fn
+        self._peak = None
+
+    def _combine(self, out_local):
+        res = gather_mix(out_local.t(), group=self.group, dst=self.dst, mix_fn=self.mix_fn, normalize="none",
+                         return_peak=True)
+        if res is None:
+            return None
+        y, peak = res
+        self._peak = peak if self._peak is None else self._peak.maximum(peak)
+        return y
+
+    def process(self, block_local, elev_local, azim_local):
+        """block_local [len(self.sources), B] and the trajectories of THIS rank's sources."""
+        return self._combine(self.local.process(block_local, elev_local, azim_local))
+
+    def finish(self):
+        return self._combine(self.local.finish())
+
+    @property
+    def peak(self):
+        return None if self._peak is None else float(self._peak.reshape(-1)[0])

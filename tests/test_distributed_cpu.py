@@ -94,6 +94,80 @@ def _worker_time(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
+class _CpuStream:
+    """Oracle stand-in for StreamRenderer: keeps the whole history and re-renders it (test sizes only)."""
+
+    def __init__(self, host, n_local, k, s):
+        self.host, self.n, self.k, self.s = host, n_local, k, s
+        self.x = np.zeros((n_local, 0))
+        self.elev = self.azim = None
+        self.emitted = 0
+
+    def _render(self, pad_chunks=0):
+        x = np.concatenate([self.x, np.zeros((self.n, pad_chunks * self.k))], axis=1)
+        e, a = self.elev, self.azim
+        for _ in range(pad_chunks):
+            e, a = np.concatenate([e, e[:, -1:]], axis=1), np.concatenate([a, a[:, -1:]], axis=1)
+        irs = [np.stack([orc.interp2d(self.host, e[i, c], a[i, c]) for c in range(e.shape[1])]) for i in range(self.n)]
+        return orc.render_mix(x, self.k, self.s, irs, normalize=False)
+
+    def process(self, block, elev, azim):
+        self.x = np.concatenate([self.x, np.asarray(block)], axis=1)
+        self.elev = elev if self.elev is None else np.concatenate([self.elev, elev[:, 1:]], axis=1)
+        self.azim = azim if self.azim is None else np.concatenate([self.azim, azim[:, 1:]], axis=1)
+        y = self._render()
+        out = y[self.emitted:self.x.shape[1]]
+        self.emitted = self.x.shape[1]
+        return torch.from_numpy(out.copy())
+
+    def finish(self):
+        y = self._render()
+        return torch.from_numpy(y[self.emitted:self.emitted + L - 1].copy())
+
+
+def _worker_stream(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    host, sigs, elev, azim = _scene()
+    in_length, _ = orc.render_lengths(N, K, L)
+    x = np.zeros((N_SRC, in_length))
+    x[:, :N] = sigs
+    st = bas.distributed.ShardedStreamRenderer(None, N_SRC, K, S, mix_fn=_cpu_mix,
+                                               stream_factory=lambda t, n, k, s: _CpuStream(host, n, k, s))
+    sl = slice(st.sources.start, st.sources.stop)
+    outs = []
+    B = 3 * K
+    for b0 in range(0, in_length, B):
+        c0 = b0 // K
+        outs.append(st.process(x[sl, b0:b0 + B], elev[sl, c0:c0 + B // K + 1], azim[sl, c0:c0 + B // K + 1]))
+    outs.append(st.finish())
+    if rank == 0:
+        y = torch.cat(outs, dim=0).numpy()
+        np.save(out_path, np.concatenate([y, np.full((1, 2), st.peak)], axis=0))
+    else:
+        assert all(o is None for o in outs) and st.peak is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_stream_matches_whole_render(tmp_path):
+    out = str(tmp_path / "stream.npy")
+    mp.spawn(_worker_stream, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    host, sigs, elev, azim = _scene()
+    irs = [np.stack([orc.interp2d(host, elev[i, c], azim[i, c]) for c in range(elev.shape[1])]) for i in range(N_SRC)]
+    ref = orc.render_mix(sigs, K, S, irs, normalize=False)
+    assert got.shape[0] - 1 == ref.shape[0]
+    assert np.abs(got[:-1] - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert got[-1, 0] == pytest.approx(np.abs(got[:-1]).max(), rel=1e-6)
+
+
+def test_sharded_stream_needs_a_source_per_rank():
+    with pytest.raises(ValueError):
+        bas.distributed.ShardedStreamRenderer(None, 0, K, S, stream_factory=lambda *a: None)
+
+
 def test_shard_time_partition():
     for n, w in ((863, 8), (6, 2), (3, 4), (337500, 8)):
         r = [bas.distributed.shard_time(n, w, k) for k in range(w)]

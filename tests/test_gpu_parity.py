@@ -295,6 +295,33 @@ def test_streaming_equals_whole(dev_tables, tables, l, k, s, blocks):
     assert rel_err(whole.cpu().numpy(), orc.render_mix(sigs, k, s, irs, normalize=False)) <= REL
 
 
+def test_sharded_stream_single_rank_equals_stream(dev_tables):
+    """distributed.ShardedStreamRenderer without a process group: the HIP gather/sum path (bas_mix_partials_f32
+    on one part) must hand back exactly what StreamRenderer emits, and track the same peak."""
+    import torch
+    h, d = dev_tables[("consistent", 128)]
+    n_src, k, s, blocks = 4, 512, 32, (1024, 2048)
+    n = sum(blocks)
+    sigs = np.stack([bas.synth.integer_noise(60 + i, n, 0.1) for i in range(n_src)])
+    t = np.arange(0, n + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        elev[i], azim[i] = bas.synth.trajectory("spiral", period_s=0.05 + 0.01 * i, length_s=n / 44100, turns=2.0)(t)
+    a = bas.StreamRenderer(d, n_src, k, s)
+    b = bas.distributed.ShardedStreamRenderer(d, n_src, k, s)
+    assert list(b.sources) == list(range(n_src))
+    pos = 0
+    for blk in blocks:
+        c0, c1 = pos // k, (pos + blk) // k
+        ya = a.process(sigs[:, pos:pos + blk], elev[:, c0:c1 + 1], azim[:, c0:c1 + 1])
+        yb = b.process(sigs[:, pos:pos + blk], elev[:, c0:c1 + 1], azim[:, c0:c1 + 1])
+        assert torch.equal(ya, yb)
+        pos += blk
+    assert torch.equal(a.finish(), b.finish())
+    assert b.peak == pytest.approx(a.peak, rel=1e-7)
+
+
 def test_cli_harness(tmp_path, tables):
     """WAV in -> WAV out with the reference's naming, presets and normalisation."""
     import scipy.io.wavfile as wavfile
