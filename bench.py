@@ -56,6 +56,7 @@ def parse():
                          "rendered block by block with carried state, inputs and trajectories generated on the device")
     ap.add_argument("--fs", type=int, default=FS)
     ap.add_argument("--block", type=int, default=262144, help="stream mode: input samples per block")
+    ap.add_argument("--regen", action="store_true", help="stream mode: draw a fresh random block inside every timed step")
     ap.add_argument("--cpu-sources-per-core", type=int, default=16)
     return ap.parse_args()
 
@@ -173,12 +174,18 @@ def stream_mode(args):
     gen = torch.Generator(device=dev).manual_seed(5 + rank)
     gloo = world > 1 and dist.get_backend() == "gloo"
 
+    # the input block lives in the renderer's own input buffer (what a decoder / H2D copy would fill in place):
+    # resident in HBM when a timed step starts, as the bench contract asks; --regen draws a fresh block per step
+    xin = st.local.input_view(B)
+    xin.copy_((torch.rand((n_src, B), generator=gen, device=dev) * 2 - 1) * (1.0 / n_total))
+
     def block(i):
         t = (torch.arange(B // k + 1, dtype=torch.float64, device=dev)[None, :] * k + i * B)
         elev = (math.pi / 4) * torch.cos(2 * math.pi * t / period + phase)          # askew circles, per-source period
         azim = 2 * math.pi * t / period + phase
-        x = (torch.rand((n_src, B), generator=gen, device=dev) * 2 - 1) * (1.0 / n_total)
-        return x, elev, azim
+        if args.regen:
+            xin.copy_((torch.rand((n_src, B), generator=gen, device=dev) * 2 - 1) * (1.0 / n_total))
+        return xin, elev, azim
 
     def step(i):
         if not gloo:
@@ -209,7 +216,7 @@ def stream_mode(args):
         print(json.dumps({"metric": "streaming render, x real-time", "value": audio_s / el, "unit": "x real-time",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "strong", "dtype": "f32",
-                          "data": "synthetic (generated on device, included in time)",
+                          "data": "synthetic; input block resident in the renderer's input buffer" + (" (redrawn every step, included in time)" if args.regen else "") + ", trajectories computed per block on the device (included in time)",
                           "config": {"workload": f"BASELINE config 5 shape: {n_total} sources @ {fs} Hz streamed in blocks of {B} "
                                                  f"samples, chunk {k}, subchunk {s}, {l} taps; sources sharded over {world} GPU(s), "
                                                  f"one gather per block", "block": B},

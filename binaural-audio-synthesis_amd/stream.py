@@ -28,13 +28,30 @@ class StreamRenderer:
         L = self.tbl.L
         self.halo = -(-(L - 1) // self.K) * self.K if L > 1 else 0
         dev = self.tbl.device
-        self._x_halo = torch.zeros((self.n_src, self.halo), dtype=torch.float32, device=dev)
+        # input staging buffer [n_src, halo + capacity]: columns [0, halo) carry the previous inputs, a block
+        # is rendered in place behind them (input_view() lets a producer write there directly: no copy)
+        self._xbuf = torch.zeros((self.n_src, self.halo), dtype=torch.float32, device=dev)
         self._idx_halo = None          # parameters at the halo's chunk boundaries, [n_src, halo/K, 4|3]
         self._w_halo = None
         self._idx_last = self._w_last = None
         self._peak_dev = torch.zeros((), dtype=torch.float32, device=dev)
         self.samples_in = 0
         self._finished = False
+
+    def _reserve(self, B):
+        import torch
+        cap = self._xbuf.shape[1] - self.halo
+        if cap < B:
+            grown = torch.zeros((self.n_src, self.halo + (B + 3) // 4 * 4), dtype=torch.float32, device=self._xbuf.device)
+            grown[:, :self.halo] = self._xbuf[:, :self.halo]
+            self._xbuf = grown
+
+    def input_view(self, B):
+        """Device view [n_src, B] of the renderer's own input buffer.  A producer (decoder, H2D copy,
+        another kernel) that writes the next block here and passes this view to process() saves the
+        staging copy of the block; the view is valid until the next input_view() call with a larger B."""
+        self._reserve(B)
+        return self._xbuf[:, self.halo:self.halo + B]
 
     def process(self, block, elev, azim):
         """block: [n_src, B] (B a multiple of the chunk size); elev/azim: float64 [n_src, B/K + 1],
@@ -63,15 +80,19 @@ class StreamRenderer:
             self._w_halo = w[:, :1].repeat(1, nh, 1)
         idx_all = torch.cat([self._idx_halo, idx], dim=1)              # boundaries t0-halo .. t0+B
         w_all = torch.cat([self._w_halo, w], dim=1)
-        x = torch.empty((self.n_src, self.halo + B), dtype=torch.float32, device=dev)
-        x[:, :self.halo] = self._x_halo
-        x[:, self.halo:] = blk.to(device=dev, dtype=torch.float32)
+        self._reserve(B)
+        x = self._xbuf[:, :self.halo + B]
+        in_place = blk.is_cuda and blk.dtype == torch.float32 and blk.stride() == x.stride() and \
+            blk.data_ptr() == self._xbuf.data_ptr() + 4 * self.halo
+        if not in_place:
+            x[:, self.halo:] = blk.to(device=dev, dtype=torch.float32)
         y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_all.reshape(-1, 4).contiguous(),
                                     w_all.reshape(-1, 3).contiguous(), normalize="none")
         out = y[:, self.halo:self.halo + B]
         # carry: last `halo` inputs and the parameters of their chunk boundaries (t0+B-halo .. t0+B-K)
         if self.halo:
-            self._x_halo = x[:, B:B + self.halo].clone()
+            tail = x[:, B:B + self.halo]
+            self._xbuf[:, :self.halo] = tail.clone() if B < self.halo else tail      # ranges overlap only if B < halo
             self._idx_halo = idx_all[:, nb - 1:nb - 1 + nh].clone()
             self._w_halo = w_all[:, nb - 1:nb - 1 + nh].clone()
         self._idx_last, self._w_last = idx[:, -1:].clone(), w[:, -1:].clone()   # boundary t0 + B
@@ -96,7 +117,7 @@ class StreamRenderer:
         dev = self.tbl.device
         idx_all = torch.cat([self._idx_halo, self._idx_last, self._idx_last], dim=1)
         w_all = torch.cat([self._w_halo, self._w_last, self._w_last], dim=1)
-        x = torch.cat([self._x_halo, torch.zeros((self.n_src, self.K), dtype=torch.float32, device=dev)], dim=1)
+        x = torch.cat([self._xbuf[:, :self.halo], torch.zeros((self.n_src, self.K), dtype=torch.float32, device=dev)], dim=1)
         y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_all.reshape(-1, 4).contiguous(),
                                     w_all.reshape(-1, 3).contiguous(), normalize="none")
         out = y[:, self.halo:self.halo + L - 1]

@@ -295,6 +295,35 @@ def test_streaming_equals_whole(dev_tables, tables, l, k, s, blocks):
     assert rel_err(whole.cpu().numpy(), orc.render_mix(sigs, k, s, irs, normalize=False)) <= REL
 
 
+def test_stream_input_view_is_zero_copy_and_equal(dev_tables):
+    """A producer writing blocks straight into StreamRenderer.input_view() gets the same audio as one
+    handing over separate tensors (blocks shorter and longer than the halo, growing capacity)."""
+    import torch
+    h, d = dev_tables[("consistent", 128)]
+    n_src, k, s, blocks = 3, 64, 32, (64, 256, 64, 1024)          # halo = 128: first and third block are shorter
+    n = sum(blocks)
+    sigs = torch.from_numpy(np.stack([bas.synth.integer_noise(80 + i, n, 0.1) for i in range(n_src)])).float().cuda()
+    t = np.arange(0, n + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        elev[i], azim[i] = bas.synth.trajectory("circle_askew", period_s=0.03 + 0.01 * i, length_s=n / 44100)(t)
+    a = bas.StreamRenderer(d, n_src, k, s)
+    b = bas.StreamRenderer(d, n_src, k, s)
+    pos = 0
+    for blk in blocks:
+        c0, c1 = pos // k, (pos + blk) // k
+        ya = a.process(sigs[:, pos:pos + blk], elev[:, c0:c1 + 1], azim[:, c0:c1 + 1])
+        view = b.input_view(blk)
+        view.copy_(sigs[:, pos:pos + blk])
+        ptr = b._xbuf.data_ptr()
+        yb = b.process(view, elev[:, c0:c1 + 1], azim[:, c0:c1 + 1])
+        assert b._xbuf.data_ptr() == ptr                               # rendered in place, nothing reallocated
+        assert torch.equal(ya, yb)
+        pos += blk
+    assert torch.equal(a.finish(), b.finish())
+
+
 def test_sharded_stream_single_rank_equals_stream(dev_tables):
     """distributed.ShardedStreamRenderer without a process group: the HIP gather/sum path (bas_mix_partials_f32
     on one part) must hand back exactly what StreamRenderer emits, and track the same peak."""
