@@ -9,4 +9,5 @@ from .stream import StreamRenderer  # noqa: F401
 from .apply_hrtf import (  # noqa: F401
     load_irs_and_delaydiffs, irs_and_delaydiffs, interpolate_2d, interpolate_2d_deg, interpolate_2d_batch,
     interpolate_2d_params, make_signal_move_2d, render_sources, delay_signal_float,
-    delay_compensated_interpolation_with_delaydiff)
+    delay_compensated_interpolation_with_delaydiff, delay_compensated_interpolation,
+    delay_compensated_interpolation_easy, make_signal_move)

@@ -122,6 +122,27 @@ def delay_compensated_interpolation_with_delaydiff(irs_and_delaydiffs, before: i
     return (d[0, 0], d[0, 1], out[0].cpu().numpy())
 
 
+def delay_compensated_interpolation(irs_and_delaydiffs, before: int, after: int, alpha: float):
+    """Same as above but discard the delay differences (apply_hrtf.py:108-111)."""
+    return delay_compensated_interpolation_with_delaydiff(irs_and_delaydiffs, before, after, alpha)[2]
+
+
+def ring_easy_params(continuous_index):
+    """(before, after, alpha) of delay_compensated_interpolation_easy (apply_hrtf.py:116-122), with the
+    reference's hard-wired wrap of the horizontal ring (after == 97 -> 73)."""
+    before = int(np.floor(continuous_index))
+    after = int(np.ceil(continuous_index))
+    alpha = continuous_index - before
+    if after == 97:
+        after = 73
+    return before, after, alpha
+
+
+def delay_compensated_interpolation_easy(irs_and_delaydiffs, continuous_index: float):
+    """Ring interpolation addressed by one continuous database index (apply_hrtf.py:114-125)."""
+    return delay_compensated_interpolation(irs_and_delaydiffs, *ring_easy_params(continuous_index))
+
+
 # --------------------------------------------------------------------------
 # a6
 # --------------------------------------------------------------------------
@@ -335,4 +356,48 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
         print(' 100.0%      ')
     out = y.t()                                                              # (out_length, 2), F-ordered like :459
     assert out.shape[0] == out_length, 'wrong output length'
+    return out if is_tensor else out.cpu().numpy()
+
+
+def make_signal_move(in_signal, chunksize: int, index_function, irs_and_delaydiffs, verbose=False):
+    """The reference's older 1-D renderer (apply_hrtf.py:294-353): one ring-interpolated IR per chunk
+    (delay_compensated_interpolation_easy at the chunk's first sample, :331), no crossfade, direct FIR,
+    overlap-add, float32, peak rule.  On the device this is bas_ring_interp_f32 for all chunks at once
+    followed by bas_render_mix_f32 with subchunk = chunk (crossfade weight 0 throughout, so the extra
+    IR the kernel's layout wants at t = in_length is never used: the last one is repeated).
+    Returns (out_length, 2) float32 (numpy for numpy input, device tensor for a device tensor)."""
+    import torch
+    is_tensor = isinstance(in_signal, torch.Tensor)
+    assert len(in_signal.shape) == 1, 'only mono signals for now'            # :306
+    tbl = as_device_table(irs_and_delaydiffs)
+    dev = tbl.device
+    n = int(in_signal.shape[0])
+    in_length, out_length = render_lengths(n, chunksize, tbl.L)              # :309-315
+    n_chunks = in_length // chunksize
+    pq = np.empty((n_chunks + 1, 2), dtype=np.int32)
+    al = np.empty((n_chunks + 1,), dtype=np.float64)
+    for c in range(n_chunks):                                                # :328, :331
+        b, a, alpha = ring_easy_params(index_function(c * chunksize))
+        if not (0 <= b < tbl.ndir and 0 <= a < tbl.ndir):
+            raise IndexError("HRTF database index out of range")
+        pq[c], al[c] = (b, a), alpha
+        if verbose and c % 64 == 0:
+            print(' {:.1f}%           '.format(100 * c * chunksize / max(in_length, 1)), end='\r')
+    if n_chunks:
+        pq[n_chunks], al[n_chunks] = pq[n_chunks - 1], al[n_chunks - 1]
+    else:
+        pq[0], al[0] = (0, 0), 0.0
+    pq_t = torch.from_numpy(pq).to(dev)
+    al_t = torch.from_numpy(al).to(dev)
+    H = torch.empty((1, n_chunks + 1, 2, tbl.L), dtype=torch.float32, device=dev)
+    _hip.call("bas_ring_interp_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(pq_t), _hip.ptr(al_t),
+              n_chunks + 1, tbl.ndir, tbl.L, tbl.upsampling, 0, _hip.ptr(H), None, _hip.current_stream(dev))
+    x = torch.zeros((1, in_length), dtype=torch.float32, device=dev)         # :309-310
+    src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
+    x[0, :n] = src.to(device=dev, dtype=torch.float32)
+    y, _ = render_device(x, int(chunksize), int(chunksize), H, tbl.L, "mix")
+    if verbose:
+        print(' 100.0%      ')
+    out = y.t()
+    assert out.shape[0] == out_length, 'wrong output length'                 # :315
     return out if is_tensor else out.cpu().numpy()

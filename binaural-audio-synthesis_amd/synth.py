@@ -223,6 +223,17 @@ def trajectory(name, fs=44100, period_s=4.0, length_s=30.0, turns=15.0, phase=0.
     return wrapped
 
 
+def index_function(name, n):
+    """Continuous database index over a signal of n samples, for the legacy 1-D path
+    (make_signal_move, apply_hrtf.py:294): indices 73..97 are the block its 97 -> 73 wrap serves."""
+    table = {
+        "ring0_sweep": lambda t: 73.0 + 23.75 * (t / n),              # ends just short of the wrap
+        "ring0_wrap": lambda t: 73.0 + (24.0 * 3 * t / n) % 24.0,      # three turns through the wrap
+        "low_ring": lambda t: 3.0 + 15.5 * (t / n),                    # inside the lowest ring
+    }
+    return table[name]
+
+
 def integer_noise(seed, n, scale=1.0):
     """Seeded white noise in [-1,1) * scale, exactly representable in float32 and
     identical on every machine (integer draws only)."""

@@ -241,3 +241,42 @@ def render_mix(signals, chunksize, subchunksize, irs_per_source, normalize=True)
         acc = out if acc is None else acc + out
     res = acc.astype(np.float32).T
     return peak_normalize(res) if normalize else res
+
+
+# --------------------------------------------------------------------------
+# legacy 1-D path: apply_hrtf.py:108-125, :294-353
+# --------------------------------------------------------------------------
+def ring_interp_irs(tbl, before, after, alpha):            # apply_hrtf.py:108-111
+    return ring_interp(tbl, before, after, alpha)[2]
+
+
+def ring_easy_params(continuous_index):
+    """(before, after, alpha) of delay_compensated_interpolation_easy (apply_hrtf.py:114-125),
+    including its hard-wired wrap of the horizontal ring (after 97 -> 73, :121-122)."""
+    before = int(np.floor(continuous_index))               # :116
+    after = int(np.ceil(continuous_index))                 # :117
+    alpha = continuous_index - before                      # :118
+    if after == 97:                                        # :121-122
+        after = 73
+    return before, after, alpha
+
+
+def ring_easy(tbl, continuous_index):
+    return ring_interp_irs(tbl, *ring_easy_params(continuous_index))
+
+
+def render_1d(in_signal, chunksize, index_function, tbl, normalize=True):
+    """Restatement of make_signal_move (apply_hrtf.py:294-353): ONE ring-interpolated IR per chunk
+    (taken at the chunk's first sample, :331), no crossfade, direct FIR of the whole chunk, overlap-add."""
+    x = np.asarray(in_signal)
+    assert x.ndim == 1                                     # :306
+    l = ir_length(tbl)                                     # :307
+    in_length, out_length = render_lengths(x.size, chunksize, l)   # :309-315
+    x = np.concatenate([x.astype(np.float64), np.zeros(in_length - x.size)])
+    out = np.zeros((2, out_length))
+    for i in range(0, in_length, chunksize):               # :328
+        h = ring_easy(tbl, index_function(i))              # :331
+        out[0, i: i + chunksize + l - 1] += np.convolve(x[i: i + chunksize], h[0])   # :334, :339
+        out[1, i: i + chunksize + l - 1] += np.convolve(x[i: i + chunksize], h[1])   # :335, :340
+    out = out.astype(np.float32).T                         # :347
+    return peak_normalize(out) if normalize else out       # :349-351

@@ -112,6 +112,39 @@ def test_make_signal_move_2d_pyfloat_trajectory(dev_tables):
     assert rel_err(got, g["y"]) <= REL
 
 
+LEGACY_CASES = ["ring0_sweep_512_128", "ring0_wrap_256_100", "low_ring_500_128", "loud_512_128"]
+
+
+@pytest.mark.parametrize("name", LEGACY_CASES)
+def test_make_signal_move_legacy_golden(dev_tables, tables, name):
+    """the reference's older 1-D renderer (apply_hrtf.py:294-353) on the same kernels."""
+    g = golden(f"render1d_{name}.npz")
+    meta = json.loads(str(g["meta"]))
+    if (meta["table"], meta["L"]) in dev_tables:
+        _, d = dev_tables[(meta["table"], meta["L"])]
+    else:
+        h = tables[meta["table"]].truncated(meta["L"])
+        d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    got = bas.make_signal_move(g["x"], meta["K"], bas.synth.index_function(meta["index_function"], meta["n"]), d)
+    assert isinstance(got, np.ndarray) and got.dtype == np.float32 and got.shape == g["y"].shape
+    assert rel_err(got, g["y"]) <= REL, rel_err(got, g["y"])
+
+
+def test_legacy_ring_easy_golden(dev_tables):
+    g = golden("legacy_ring_easy.npz")
+    for tname in ("consistent", "adversarial"):
+        _, d = dev_tables[(tname, 128)]
+        for i, ci in enumerate(g["ci"]):
+            got = bas.delay_compensated_interpolation_easy(d, float(ci))
+            assert got.shape == (2, 128) and rel_err(got, g[f"{tname}_easy"][i]) <= REL
+        for i, (p, q, a) in enumerate(((72, 73, 0.3), (10, 11, 0.0), (186, 186, 0.5))):
+            assert rel_err(bas.delay_compensated_interpolation(d, p, q, a), g[f"{tname}_plain"][i]) <= REL
+    with pytest.raises(IndexError):
+        bas.make_signal_move(np.zeros(600, dtype=np.float32), 512, lambda t: 186.5, dev_tables[("consistent", 128)][1])
+    with pytest.raises(AssertionError):
+        bas.make_signal_move(np.zeros((4, 2), dtype=np.float32), 512, lambda t: 80.0, dev_tables[("consistent", 128)][1])
+
+
 def test_reference_error_behaviour(dev_tables):
     _, d = dev_tables[("consistent", 128)]
     traj = bas.synth.trajectory("circle_horizontal")

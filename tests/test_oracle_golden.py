@@ -113,3 +113,28 @@ def test_render_mix_of_one_source_is_render(tables):
     irs = orc.chunk_irs(tb, 512, in_length, traj)
     got = orc.render_mix([g["x"]], 512, 32, [irs])
     assert np.array_equal(got, g["y"])
+
+
+# ---- legacy 1-D path (apply_hrtf.py:108-125, :294-353), goldens from tests/golden/make_golden_legacy.py
+LEGACY_CASES = ["ring0_sweep_512_128", "ring0_wrap_256_100", "low_ring_500_128", "loud_512_128"]
+
+
+@pytest.mark.parametrize("tname", ["consistent", "adversarial"])
+def test_legacy_ring_easy(tables, tname):
+    g = golden("legacy_ring_easy.npz")
+    tb = tables[tname].truncated(128)
+    for i, ci in enumerate(g["ci"]):
+        assert np.array_equal(orc.ring_easy(tb, float(ci)), g[f"{tname}_easy"][i]), ci
+    for i, (p, q, a) in enumerate(((72, 73, 0.3), (10, 11, 0.0), (186, 186, 0.5))):
+        assert np.array_equal(orc.ring_interp_irs(tb, p, q, a), g[f"{tname}_plain"][i])
+    assert orc.ring_easy_params(96.5) == (96, 73, 0.5)          # the hard-wired wrap, apply_hrtf.py:121-122
+
+
+@pytest.mark.parametrize("name", LEGACY_CASES)
+def test_legacy_render_1d(tables, name):
+    g = golden(f"render1d_{name}.npz")
+    meta = json.loads(str(g["meta"]))
+    tb = tables[meta["table"]].truncated(meta["L"])
+    got = orc.render_1d(g["x"], meta["K"], bas.synth.index_function(meta["index_function"], meta["n"]), tb)
+    assert got.dtype == np.float32 and np.array_equal(got, g["y"])
+    assert (np.abs(g["y"]).max() == 1.0) == name.startswith("loud")
