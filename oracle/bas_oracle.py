@@ -280,3 +280,26 @@ def render_1d(in_signal, chunksize, index_function, tbl, normalize=True):
         out[1, i: i + chunksize + l - 1] += np.convolve(x[i: i + chunksize], h[1])   # :335, :340
     out = out.astype(np.float32).T                         # :347
     return peak_normalize(out) if normalize else out       # :349-351
+
+
+def render_window(x_win, m_first, chunksize, subchunksize, ir_of, l, n0, n1):
+    """Output samples [n0, n1) of ONE source's un-normalised render, straight from the definition of
+    apply_hrtf.py:431-453 (float64): input sample m lies in chunk c = m // K, subchunk start
+    j = ((m % K) // S) * S, and is filtered with g = (1 - j/K) H_c + (j/K) H_{c+1} (:442-446).
+    x_win holds the input samples m_first .. m_first + len(x_win) - 1 (must cover max(n0-l+1, 0) .. n1-1
+    as far as the signal exists); ir_of(c) -> (2, l) chunk IR.  Used for spot checks at sizes where the
+    whole-signal restatement is too slow."""
+    out = np.zeros((2, n1 - n0))
+    x_win = np.asarray(x_win, dtype=np.float64)
+    g_cache = {}
+    for m in range(max(n0 - l + 1, m_first, 0), min(n1, m_first + x_win.size)):
+        c = m // chunksize
+        j = ((m % chunksize) // subchunksize) * subchunksize
+        if (c, j) not in g_cache:
+            alpha = j / chunksize
+            g_cache[(c, j)] = (1 - alpha) * ir_of(c) + alpha * ir_of(c + 1)
+        g = g_cache[(c, j)]
+        lo, hi = max(n0, m), min(n1, m + l)                 # outputs this input sample reaches
+        if hi > lo:
+            out[:, lo - n0:hi - n0] += x_win[m - m_first] * g[:, lo - m:hi - m]
+    return out

@@ -293,6 +293,46 @@ def test_linearity_and_determinism_at_full_size(dev_tables):
     assert ya.shape == (in_length + 127, 2)
 
 
+def test_oracle_spot_checks_at_baseline_size(dev_tables):
+    """BASELINE config 4 on one GPU (256 sources x 10 s, K=512, S=32, L=128): windows of the mix checked
+    directly against the oracle's float64 definition (start, a chunk boundary, a tile boundary of the FIR
+    kernel, the middle of a chunk, the L-1 tail)."""
+    import torch
+    h, d = dev_tables[("consistent", 128)]
+    n_src, n, k, s, l = 256, 441000, 512, 32, 128
+    in_length, out_length = orc.render_lengths(n, k, l)
+    t = np.arange(0, in_length + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        name = "spiral" if i % 2 == 0 else "circle_askew"
+        tr = bas.synth.trajectory(name, period_s=2.0 + i / 64.0, length_s=10.0, turns=5.0, phase=2 * np.pi * i / n_src)
+        elev[i], azim[i] = tr(t)
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    x = (torch.rand((n_src, n), generator=gen, device="cuda") * 2 - 1) * (1.0 / n_src)
+    y = bas.render_sources(x, k, s, elev, azim, d, normalize="none")
+    assert y.shape == (out_length, 2)
+    scale = float(y.abs().max())
+    windows = [(0, 48), (430 * k - 24, 430 * k + 24), (20 * 8192 - 24, 20 * 8192 + 24), (300 * k + 250, 300 * k + 282),
+               (out_length - 48, out_length)]
+    worst = 0.0
+    for n0, n1 in windows:
+        m0, m1 = max(n0 - l + 1, 0), min(n1, n)
+        xw = x[:, m0:m1].double().cpu().numpy()
+        want = np.zeros((2, n1 - n0))
+        for i in range(n_src):
+            cache = {}
+
+            def ir_of(c, i=i, cache=cache):
+                if c not in cache:
+                    cache[c] = orc.interp2d(h, elev[i, c], azim[i, c])
+                return cache[c]
+            want += orc.render_window(xw[i], m0, k, s, ir_of, l, n0, n1)
+        got = y[n0:n1].double().cpu().numpy().T
+        worst = max(worst, float(np.abs(got - want).max()) / scale)
+    assert worst <= REL, worst
+
+
 @pytest.mark.parametrize("l,k,s,blocks", [(128, 512, 32, (4096, 512, 8192, 1024)), (100, 512, 64, (2048, 2048)),
                                           (300, 512, 32, (1024, 3072)), (128, 128, 32, (1280, 2560))])
 def test_streaming_equals_whole(dev_tables, tables, l, k, s, blocks):

@@ -138,3 +138,19 @@ def test_legacy_render_1d(tables, name):
     got = orc.render_1d(g["x"], meta["K"], bas.synth.index_function(meta["index_function"], meta["n"]), tb)
     assert got.dtype == np.float32 and np.array_equal(got, g["y"])
     assert (np.abs(g["y"]).max() == 1.0) == name.startswith("loud")
+
+
+def test_render_window_agrees_with_whole_render(tables):
+    """The windowed definition used for full-size GPU spot checks equals the loop restatement."""
+    g = golden("render_spiral_512_32_128.npz")
+    meta = json.loads(str(g["meta"]))
+    tb = tables["consistent"].truncated(128)
+    traj = bas.synth.trajectory(meta["traj"], fs=meta["fs"], **meta["traj_kw"])
+    x = g["x"]
+    in_length, out_length = orc.render_lengths(x.size, 512, 128)
+    irs = orc.chunk_irs(tb, 512, in_length, traj)
+    xp = np.concatenate([x, np.zeros(in_length - x.size)])
+    for n0, n1 in ((0, 70), (480, 560), (5000, 5100), (out_length - 90, out_length)):
+        m0 = max(n0 - 127, 0)
+        got = orc.render_window(xp[m0:min(n1, in_length)], m0, 512, 32, lambda c: irs[c], 128, n0, n1)
+        assert np.abs(got.T - g["y"][n0:n1]).max() <= 1e-6 * np.abs(g["y"]).max()
