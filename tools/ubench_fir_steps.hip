@@ -219,10 +219,10 @@ __global__ __launch_bounds__(256, 2) void k(float *out, const float *in, int ite
 }
 
 template <int V>
-static void run(float *out, const float *in) {
-    const int iters = 400, blocks = 512;
+static void run(float *out, const float *in, int blocks = 512) {
+    const int iters = 400;
     static float *gx = nullptr;
-    if (!gx) { (void)hipMalloc(&gx, (size_t)blocks * iters * 2340 * 16 + (1 << 20)); (void)hipMemset(gx, 0x3c, (size_t)blocks * iters * 2340 * 16 + (1 << 20)); }
+    if (!gx) { (void)hipMalloc(&gx, (size_t)512 * iters * 2340 * 16 + (1 << 20)); (void)hipMemset(gx, 0x3c, (size_t)512 * iters * 2340 * 16 + (1 << 20)); }
     const size_t lds = 8 * XR * 16 + 18 * SLOT * 4;
     (void)hipFuncSetAttribute((const void *)k<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
@@ -235,8 +235,8 @@ static void run(float *out, const float *in) {
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     double pk = (V >= 4 ? 4096.0 / 5 : 1024.0) * iters;
     double flops = pk * 4 * 64 * 4 * blocks;
-    printf("V%d: %.3f ms, %.1f TFLOP/s (%.2f cycles per FIR v_pk_fma_f32 per SIMD at 2.0 GHz)  %s\n", V, ms,
-           flops / (ms * 1e-3) / 1e12, (ms * 1e-3 * 2.0e9) / (pk * 2), hipGetErrorString(hipGetLastError()));
+    printf("V%d (%d WG/CU): %.3f ms, %.1f TFLOP/s (%.2f cycles per FIR v_pk_fma_f32 per SIMD at 2.0 GHz)  %s\n", V, blocks / 256, ms,
+           flops / (ms * 1e-3) / 1e12, (ms * 1e-3 * 2.0e9) / (pk * (blocks / 256)), hipGetErrorString(hipGetLastError()));
 }
 
 int main() {
@@ -250,5 +250,6 @@ int main() {
         (void)hipMemcpy(in, hbuf, 8192, hipMemcpyHostToDevice);
     }
     run<0>(out, in); run<1>(out, in); run<2>(out, in); run<3>(out, in); run<4>(out, in); run<5>(out, in); run<6>(out, in); run<9>(out, in); run<11>(out, in); run<12>(out, in);
+    run<0>(out, in, 256); run<3>(out, in, 256); run<5>(out, in, 256); run<11>(out, in, 256);
     return 0;
 }
