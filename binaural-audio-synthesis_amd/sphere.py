@@ -13,6 +13,8 @@ the scalar function keeps numpy's promotion rules (a Python-float azimuth is
 handled in float32, an np.float64 azimuth in float64).  The vectorised form
 implements the np.float64 branch.
 """
+import bisect
+
 import numpy as np
 
 RING_ELEVS_DEG = (-45, -30, -15, 0, 15, 30, 45, 60, 75, 90)
@@ -79,9 +81,8 @@ def elevation_bracket(elev):
     return lower, higher
 
 
-def interpolation_params(elev, azim):
-    """Scalar form of everything interpolate_2d derives from the angles:
-    (top_before, top_after, bot_before, bot_after), (top_alpha, bot_alpha, a)."""
+def _interpolation_params_numpy(elev, azim):
+    """interpolation_params with the reference's own numpy expressions (any scalar types)."""
     lower, higher = elevation_bracket(elev)
     tb, ta, taf = azim_to_interpolation_params(higher, azim)      # apply_hrtf.py:214
     bb, ba, baf = azim_to_interpolation_params(lower, azim)       # :215
@@ -91,6 +92,64 @@ def interpolation_params(elev, azim):
         a = 0
     assert 0 <= a <= 1, 'interpolation parameter somehow takes invalid value'
     return (tb, taf, bb, baf), (float(ta), float(ba), float(a))
+
+
+_TWO_PI = 2 * np.pi
+_AVAIL_LIST = [float(v) for v in _AVAILABLE_ELEVS]
+_NODE_LISTS = [[float(v) for v in index_elev_azim[s:s + c, 2]] for s, c in zip(RING_START, RING_COUNTS)]   # f64(f32 node)
+
+
+def _ring_denominators(start, count):
+    """after_azim - before_azim exactly as sphere.py:119 evaluates it: both are float32 table entries (or the
+    Python float 2*pi against a float32 entry, which numpy 2 also evaluates in float32), so the difference is
+    rounded to float32 before the float64 division."""
+    den = []
+    for i in range(count):
+        before_azim = index_elev_azim[start + i, 2]
+        after_azim = index_elev_azim[start + i + 1, 2] if i + 1 < count else 2 * np.pi
+        den.append(float(after_azim - before_azim))
+    return den
+
+
+_DEN_LISTS = [_ring_denominators(s, c) for s, c in zip(RING_START, RING_COUNTS)]
+
+
+def _ring_params_f64(ring, azim):
+    """azim_to_interpolation_params on ring number `ring` for a float64 azimuth already wrapped into
+    [0, 2 pi): the np.float64 branch of sphere.py:103-119 in plain Python floats (IEEE binary64 either way;
+    float32 nodes compare and subtract as their exact binary64 values, as numpy promotes them)."""
+    if ring == 9:
+        return POLE, 0., POLE                                    # sphere.py:92-93
+    nodes = _NODE_LISTS[ring]
+    n_le = bisect.bisect_right(nodes, azim)                      # nodes ascend, node 0 is azimuth 0
+    start = RING_START[ring]
+    after = start + n_le if n_le < len(nodes) else start         # sphere.py:104-117
+    return start + n_le - 1, (azim - nodes[n_le - 1]) / _DEN_LISTS[ring][n_le - 1], after
+
+
+def interpolation_params(elev, azim):
+    """Scalar form of everything interpolate_2d derives from the angles:
+    (top_before, top_after, bot_before, bot_after), (top_alpha, bot_alpha, a).
+
+    An np.float64 azimuth (what numpy-based trajectory functions return) takes a plain-Python restatement of
+    the reference's float64 branch - same IEEE operations, ~10x less interpreter time per chunk; anything
+    else (a Python float azimuth computes in float32 under numpy 2) goes through the
+    reference's own numpy expressions."""
+    if type(azim) is not np.float64 or not (elev == elev):
+        return _interpolation_params_numpy(elev, azim)
+    azim = float(azim) % _TWO_PI                                  # sphere.py:86
+    assert azim >= 0
+    e = float(elev)
+    lo = bisect.bisect_right(_AVAIL_LIST, e) - 1                  # apply_hrtf.py:201-211 (clamped)
+    hi = bisect.bisect_left(_AVAIL_LIST, e)
+    lo = 0 if lo < 0 else lo
+    hi = 9 if hi > 9 else hi
+    tb, ta, taf = _ring_params_f64(hi, azim)
+    bb, ba, baf = _ring_params_f64(lo, azim)
+    lower, higher = _AVAIL_LIST[lo], _AVAIL_LIST[hi]
+    a = (e - lower) / (higher - lower) if higher > lower else 0.0   # :261-266
+    assert 0 <= a <= 1, 'interpolation parameter somehow takes invalid value'
+    return (tb, taf, bb, baf), (float(ta), float(ba), a)
 
 
 # ---------------------------------------------------------------------------

@@ -125,3 +125,24 @@ def test_no_gpu_fails_loudly():
         bas.irs_and_delaydiffs(t.upsampling, t.diffs_left, t.diffs_right, t.irs_left, t.irs_right)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         bas.delay_signal_float(np.zeros(8), 0.5)
+
+
+def test_fast_scalar_params_equal_the_numpy_expressions():
+    """sphere.interpolation_params takes a plain-Python path for np.float64 azimuths; it must return exactly
+    what the reference's numpy expressions give (including the float32-rounded denominators of sphere.py:119),
+    on random points and on every grid node +- eps."""
+    from binaural_audio_synthesis_amd import sphere
+    rng = np.random.default_rng(3)
+    pts = [(np.float64(e), np.float64(a)) for e, a in zip(rng.uniform(-1.2, 1.9, 3000), rng.uniform(-20, 20, 3000))]
+    for e in sphere.RING_ELEVS_DEG:
+        for de in (0.0, 1e-9, -1e-9, 1e-6, -1e-4):
+            for az in list(range(0, 361, 15)) + [359.999999, 1e-7]:
+                for dz in (0.0, 1e-9, -1e-9):
+                    pts.append((np.float64(np.deg2rad(float(e)) + de), np.float64(np.deg2rad(float(az)) + dz)))
+                    pts.append((float(np.deg2rad(float(e)) + de), np.float64(np.float32(az) * np.float32(2 * np.pi / 360)) + dz))
+    for e, a in pts:
+        assert sphere.interpolation_params(e, a) == sphere._interpolation_params_numpy(e, a), (e, a)
+    # a Python-float azimuth is NOT taken by the fast path (float32 branch of the reference under numpy 2)
+    e, a = 0.3, 4.0
+    assert sphere.interpolation_params(e, a) == sphere._interpolation_params_numpy(e, a)
+    assert sphere.interpolation_params(np.float64(e), np.float64(a))[1][0] != sphere.interpolation_params(e, a)[1][0]
