@@ -5,6 +5,7 @@ Tolerance: 1e-5 norm-relative in float32 (BASELINE.json north_star), i.e.
 max|got - want| / max|want| <= 1e-5, written REL below.
 """
 import json
+import os
 
 import numpy as np
 import pytest
@@ -552,3 +553,32 @@ def test_odd_shapes_adversarial_table(tables, l, k, s):
     want = orc.render_mix(sigs, k, s, irs, normalize=False)
     got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none").cpu().numpy()
     assert got.shape == want.shape and rel_err(got, want) <= REL
+
+
+def test_bench_contract_line():
+    """bench.py (tiny workload, child process) prints ONE JSON line carrying the contract's keys,
+    the roofline object and the CPU baseline."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BAS_BENCH_MAX_CORES="2")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--sources", "4", "--seconds", "0.5", "--steps", "2",
+                        "--warmup", "1", "--cpu-sources-per-core", "1"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    assert "traffic" in rf and rf["kernel"].startswith("bas_render_")
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0 and "sample" in cb and cb["unit"] == d["unit"]
+    assert d["value"] > cb["value"]
