@@ -6,7 +6,8 @@ reads a WAV, normalises by y.max() (:577), averages stereo to mono (:630), rende
 make_signal_move_2d and the chosen trajectory preset (:583-593; default `passing`, :633), writes
 `<in>-c<K>-s<S>-l<L>.wav` as float32 (:636-640) and prints the reference's timing line (:643-646).
 Defaults are the reference's constants (:595-598): samples_to_keep=100, chunksize=512, subchunksize=32.
-The reference's `stereo_mode` branch (self-described as possibly broken, :607-626) is not reproduced.
+`--stereo-mode` selects the reference's `stereo_mode` branch (:607-626, off by default there too): the two
+channels are rendered from two fixed directions and averaged, output `<in>-binaural-stereo.wav`.
 """
 import argparse
 import sys
@@ -40,6 +41,7 @@ def main(argv=None):
     ap.add_argument("--samples-to-keep", type=int, default=100)
     ap.add_argument("--chunksize", type=int, default=512)
     ap.add_argument("--subchunksize", type=int, default=32)
+    ap.add_argument("--stereo-mode", action="store_true", help="the reference's stereo_mode = True branch")
     args = ap.parse_args(argv)
     if args.input is None:
         print('argv[1] empty - should be input file', file=sys.stderr)      # apply_hrtf.py:570-574
@@ -56,6 +58,19 @@ def main(argv=None):
         tbl = apply_hrtf.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
     else:
         tbl = apply_hrtf.load_irs_and_delaydiffs(args.table, samples_to_keep=args.samples_to_keep)   # :602
+    if len(y.shape) == 2 and y.shape[1] == 2 and args.stereo_mode:
+        # fixed directions exactly as written at :610-611 (note `% 2*np.pi` binds as (x % 2) * pi)
+        left = lambda t: (0, ((2 * np.pi / (8 * fs) + np.pi / 2) % 2 * np.pi))            # noqa: E731
+        right = lambda t: (0, ((2 * np.pi / (8 * fs) + 3 * np.pi / 2) % 2 * np.pi))       # noqa: E731
+        left_out = apply_hrtf.make_signal_move_2d(y[:, 0], args.chunksize, args.subchunksize, left, tbl).astype(np.float32)
+        right_out = apply_hrtf.make_signal_move_2d(y[:, 1], args.chunksize, args.subchunksize, right, tbl).astype(np.float32)
+        out_sig = 0.5 * (left_out + right_out)                              # :616
+        out_filename = '{}-binaural-stereo.wav'.format(args.input.replace('.wav', ''))    # :617
+        wavfile.write(out_filename, fs, out_sig.astype(np.float32))
+        elapsed_time = time.time() - start
+        print("wrote to '{}' - took {:.2f} secs - {:.2f}x as fast as real time".format(
+            out_filename, elapsed_time, (y.size / fs) / elapsed_time))      # :620-624
+        return out_filename
     if len(y.shape) == 2 and y.shape[1] == 2:
         y = 0.5 * y[:, 0] + 0.5 * y[:, 1]                                   # :630
     out_sig = apply_hrtf.make_signal_move_2d(y, args.chunksize, args.subchunksize, traj, tbl).astype(np.float32)

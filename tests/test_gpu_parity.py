@@ -445,6 +445,26 @@ def test_cli_harness(tmp_path, tables):
     assert rel_err(got, want) <= REL
 
 
+def test_cli_stereo_mode(tmp_path, tables):
+    """The reference's stereo_mode branch (apply_hrtf.py:607-626): each channel from its fixed direction, averaged."""
+    import scipy.io.wavfile as wavfile
+    from binaural_audio_synthesis_amd import cli
+    fs, n = 44100, 5000
+    pcm = (bas.synth.integer_noise(78, n, 0.3) * 32767).astype(np.int16)
+    stereo = np.stack([pcm, np.roll(pcm, 777)], axis=1)
+    src = str(tmp_path / "s.wav")
+    wavfile.write(src, fs, stereo)
+    out = cli.main([src, "--synthetic", "--stereo-mode"])
+    assert out.endswith("s-binaural-stereo.wav")
+    _, got = wavfile.read(out)
+    y = stereo.astype(np.float32) / stereo.max()
+    tb = tables["consistent"].truncated(100)
+    left = lambda t: (0, ((2 * np.pi / (8 * fs) + np.pi / 2) % 2 * np.pi))          # noqa: E731
+    right = lambda t: (0, ((2 * np.pi / (8 * fs) + 3 * np.pi / 2) % 2 * np.pi))     # noqa: E731
+    want = 0.5 * (orc.render(y[:, 0], 512, 32, left, tb) + orc.render(y[:, 1], 512, 32, right, tb))
+    assert got.shape == want.shape and rel_err(got, want) <= REL
+
+
 def test_device_params_kernel_is_bit_identical_to_host():
     """bas_traj_params_f64 against sphere.interpolation_params_batch, incl. nodes +- eps,
     negative / large azimuths, clamped elevations and the pole."""
