@@ -602,3 +602,17 @@ def test_bench_contract_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0 and "sample" in cb and cb["unit"] == d["unit"]
     assert d["value"] > cb["value"]
+
+
+@pytest.mark.parametrize("scale", ["0.1", "3.0"])
+def test_c_caller_of_the_abi(scale):
+    """tests/cabi/cabi_check: a pure-C program (hipMalloc'd buffers, no Python in the data path) renders through
+    include/bas.h and checks itself against the oracle's plain-C restatement; scale 3.0 makes the peak rule fire."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cabi", "cabi_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe), "all"])
+    r = subprocess.run([exe, scale], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bas_render_hd_kernel" in r.stdout and "rc -2" in r.stdout

@@ -154,3 +154,34 @@ def test_render_window_agrees_with_whole_render(tables):
         m0 = max(n0 - 127, 0)
         got = orc.render_window(xp[m0:min(n1, in_length)], m0, 512, 32, lambda c: irs[c], 128, n0, n1)
         assert np.abs(got.T - g["y"][n0:n1]).max() <= 1e-6 * np.abs(g["y"]).max()
+
+
+@pytest.mark.parametrize("name", ["spiral_512_32_128", "askew_128_16_100", "loud_512_32_128", "short_512_32_128"])
+def test_c_restatement_of_the_render_loops(tables, name):
+    """oracle/bas_oracle_fir.c (the checker of the pure-C ABI caller) against the reference-generated goldens,
+    fed with the numpy oracle's chunk IRs; 1e-6 norm-relative (numpy's convolve sums in another order)."""
+    import ctypes
+    import os
+    import subprocess
+    odir = os.path.dirname(os.path.abspath(orc.__file__))
+    subprocess.check_call(["make", "-s", "-C", odir, "all"])
+    lib = ctypes.CDLL(os.path.join(odir, "libbas_oracle_fir.so"))
+    lib.bas_oracle_in_length.restype = ctypes.c_long
+    lib.bas_oracle_in_length.argtypes = [ctypes.c_long, ctypes.c_int]
+    vp = ctypes.c_void_p
+    lib.bas_oracle_render_accumulate.argtypes = [vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp]
+    lib.bas_oracle_finish.argtypes = [vp, ctypes.c_long, ctypes.c_int, vp]
+    g = golden(f"render_{name}.npz")
+    meta = json.loads(str(g["meta"]))
+    tb = tables[meta["table"]].truncated(meta["L"])
+    traj = bas.synth.trajectory(meta["traj"], fs=meta["fs"], **meta["traj_kw"])
+    x = np.ascontiguousarray(g["x"], dtype=np.float64)
+    k, s_, l = meta["K"], meta["S"], meta["L"]
+    in_length, out_length = orc.render_lengths(x.size, k, l)
+    assert lib.bas_oracle_in_length(x.size, k) == in_length
+    irs = np.ascontiguousarray(orc.chunk_irs(tb, k, in_length, traj), dtype=np.float64)
+    acc = np.zeros((2, out_length))
+    out = np.empty((out_length, 2), dtype=np.float32)
+    lib.bas_oracle_render_accumulate(x.ctypes.data, x.size, k, s_, irs.ctypes.data, l, acc.ctypes.data)
+    lib.bas_oracle_finish(acc.ctypes.data, out_length, 1, out.ctypes.data)
+    assert np.abs(out - g["y"]).max() <= 1e-6 * max(np.abs(g["y"]).max(), 1e-30)
