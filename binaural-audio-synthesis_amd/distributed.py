@@ -54,12 +54,16 @@ def gather_mix(partial, group=None, dst=0, mix_fn=None, scale_fn=None, normalize
         y, peak = mix_fn(partial.unsqueeze(0))
     else:
         rank = dist.get_rank(group)
+        # gloo cannot gather device tensors: stage through host memory (debugging / rehearsal on boxes
+        # without RCCL peers; the production backend "nccl" gathers device to device over xGMI)
+        via_host = partial.is_cuda and dist.get_backend(group) == "gloo"
+        send = partial.cpu() if via_host else partial
         if rank == dst:
-            parts = torch.empty((world,) + tuple(partial.shape), dtype=partial.dtype, device=partial.device)
-            dist.gather(partial, gather_list=list(parts.unbind(0)), dst=dst, group=group)
-            y, peak = mix_fn(parts)
+            parts = torch.empty((world,) + tuple(send.shape), dtype=send.dtype, device=send.device)
+            dist.gather(send, gather_list=list(parts.unbind(0)), dst=dst, group=group)
+            y, peak = mix_fn(parts.to(partial.device) if via_host else parts)
         else:
-            dist.gather(partial, gather_list=None, dst=dst, group=group)
+            dist.gather(send, gather_list=None, dst=dst, group=group)
             return None
     if normalize == "mix":
         y = scale_fn(y, peak)
