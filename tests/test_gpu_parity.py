@@ -659,3 +659,33 @@ def test_two_ranks_on_one_gpu_match_single_process(tmp_path, dev_tables):
     assert abs(np.abs(one).max() - 1.0) < 1e-6                              # normalised mix
     assert rel_err(got, one) <= 2e-6
     assert rel_err(got, orc.render_mix(sigs, 512, 32, irs)) <= REL
+
+
+def test_random_shape_sweep(tables):
+    """Seeded random (L, K, S, n_src, n) on the adversarial table with random (not smooth) trajectories:
+    every kernel family gets hit; where the fused path serves the shape it must agree too."""
+    rng = np.random.default_rng(20261004)
+    full = tables["adversarial"]
+    seen = set()
+    for case in range(28):
+        s_ = int(rng.choice([8, 16, 32, 32, 32, 64, 96, 128, 24, 5]))
+        k = s_ * int(rng.integers(1, 40))
+        l = int(rng.integers(1, 200))
+        n_src = int(rng.integers(1, 5))
+        n = int(rng.integers(1, 3 * k + 2500))
+        h = full.truncated(l)
+        d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+        sigs = np.stack([bas.synth.integer_noise(int(rng.integers(1e6)), n, 0.05) for _ in range(n_src)])
+        in_length, _ = orc.render_lengths(n, k, l)
+        t = np.arange(0, in_length + 1, k, dtype=np.float64)
+        elev = rng.uniform(-1.0, 1.7, size=(n_src, t.size))
+        azim = rng.uniform(-7, 7, size=(n_src, t.size))
+        irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(t.size)]) for i in range(n_src)]
+        want = orc.render_mix(sigs, k, s_, irs, normalize=False)
+        got = bas.render_sources(sigs, k, s_, elev, azim, d, normalize="none", fused=False).cpu().numpy()
+        seen.add(bas._hip.lib().bas_render_kernel_name(n_src, in_length, k, s_, l).decode())
+        assert got.shape == want.shape and rel_err(got, want) <= REL, (case, l, k, s_, n_src, n, rel_err(got, want))
+        if bas._hip.lib().bas_render_fused_supported(n_src, in_length, k, s_, l):
+            fz = bas.render_sources(sigs, k, s_, elev, azim, d, normalize="none", fused=True).cpu().numpy()
+            assert rel_err(fz, want) <= REL, (case, "fused", l, k, s_)
+    assert seen == {"bas_render_hd_kernel", "bas_render_rows32_kernel", "bas_render_generic_kernel"}, seen
