@@ -538,13 +538,19 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         }
 
         // ---- global -> registers: x window (all threads), chunk IRs of tap `tid` (threads < Lseg)
-        const float *xsrc = A.x + (long)s * A.x_stride;
+        // window offsets i = 4 (tid + 256 j) are per-thread constants; the signal's ends become two scalar
+        // bounds on them (x rows are 16-byte aligned and T_in is a multiple of 4, so a float4 is all in or out)
+        const float *xwin = A.x + (long)s * A.x_stride + xbase;
+        const long lo_l = -xbase, hi_l = A.T_in - xbase;     // offsets of the signal's first sample / one past its last
+        const int x_lo = lo_l < -(1 << 30) ? -(1 << 30) : (lo_l > (1 << 30) ? (1 << 30) : (int)lo_l);
+        const int x_hi = hi_l < -(1 << 30) ? -(1 << 30) : (hi_l > (1 << 30) ? (1 << 30) : (int)hi_l);
         f32x4 xv[HD_NX];
 #pragma unroll
         for (int j = 0; j < HD_NX; ++j) {
-            long m = xbase + 4L * (tid + j * HD_THREADS);
-            m = m < 0 ? 0 : (m > A.T_in - 4 ? A.T_in - 4 : m);
-            xv[j] = *reinterpret_cast<const f32x4 *>(xsrc + m);
+            int i = 4 * (tid + j * HD_THREADS);
+            i = i < x_lo ? x_lo : i;
+            i = i > x_hi - 4 ? x_hi - 4 : i;                 // clamped into the row (x_hi - 4 >= x_lo as T_in >= 4)
+            xv[j] = *reinterpret_cast<const f32x4 *>(xwin + i);
         }
         // chunk IRs.  Unfused: thread = (tap, half), each half of the threads stages half of the chunk
         // slots from H.  Fused: wave wv evaluates rows (slot, ear) = wv, wv+4, .. of the nslots+1 chunk
@@ -584,9 +590,8 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
 #pragma unroll
         for (int j = 0; j < HD_NX; ++j) {
             const int i4 = tid + j * HD_THREADS;
-            const long m = xbase + 4L * i4;
             f32x4 v = xv[j];
-            v = (m >= 0 && m < A.T_in) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            v = (4 * i4 >= x_lo && 4 * i4 < x_hi) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             if (i4 < nrows * 8) xs4[(i4 & 7) * HD_XR + (i4 >> 3)] = v;
         }
         if (FUSED) {
@@ -626,12 +631,15 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                 }
             }
         } else if (tap < Lseg) {
-            const float live = seg0 + tap < A.L ? 1.0f : 0.0f;   // taps >= L read as zero
+            if (seg0 + tap >= A.L) {                         // taps >= L read as zero (only when L % 8 != 0)
+#pragma unroll
+                for (int j = 0; j <= HD_HALFSLOTS; ++j) hl[j] = hr[j] = 0.f;
+            }
             f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tap;
 #pragma unroll
             for (int j = 0; j < HD_HALFSLOTS; ++j) {
                 if (slot_a + j < slot_b)
-                    dst[j * (HD_SLOT / 4)] = f32x4{hl[j], hr[j], hl[j + 1] - hl[j], hr[j + 1] - hr[j]} * live;
+                    dst[j * (HD_SLOT / 4)] = f32x4{hl[j], hr[j], hl[j + 1] - hl[j], hr[j + 1] - hr[j]};
             }
         }
         __syncthreads();
