@@ -544,6 +544,7 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         const long lo_l = -xbase, hi_l = A.T_in - xbase;     // offsets of the signal's first sample / one past its last
         const int x_lo = lo_l < -(1 << 30) ? -(1 << 30) : (lo_l > (1 << 30) ? (1 << 30) : (int)lo_l);
         const int x_hi = hi_l < -(1 << 30) ? -(1 << 30) : (hi_l > (1 << 30) ? (1 << 30) : (int)hi_l);
+        const bool x_inside = x_lo <= 0 && x_hi >= 4 * HD_NX * HD_THREADS;   // whole window inside the signal
         f32x4 xv[HD_NX];
 #pragma unroll
         for (int j = 0; j < HD_NX; ++j) {
@@ -556,10 +557,10 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         // slots from H.  Fused: wave wv evaluates rows (slot, ear) = wv, wv+4, .. of the nslots+1 chunk
         // IRs straight from the table through their read plans (one 128-byte plan per row, fetched now).
         const int tap = tid & (RT_SEG - 1);
-        const int slot_a = (tid >> 7) * ((nslots + 1) >> 1);
+        const int slot_a = __builtin_amdgcn_readfirstlane(tid >> 7) * ((nslots + 1) >> 1);   // wave-uniform: scalar slot math
         int slot_b = slot_a + ((nslots + 1) >> 1);
         if (slot_b > nslots) slot_b = nslots;
-        float hl[HD_HALFSLOTS + 1], hr[HD_HALFSLOTS + 1];
+        f32x2 hlr[HD_HALFSLOTS + 1];                         // (left, right) tap of the slots this thread stages
         constexpr int HD_MAXEVAL = (HD_MAXSLOTS + 1 + HD_NW - 1) / HD_NW;           // chunk IRs per wave
         int pword[HD_MAXEVAL];
         const int n_hslots = nslots + 1;                     // chunk IRs this pass needs
@@ -580,8 +581,8 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             for (int j = 0; j <= HD_HALFSLOTS; ++j) {
                 if (slot_a + j <= slot_b) {                  // uniform per wave
                     const float *p = Hk + (long)clampi(c0 + slot_a + j, 0, A.n_chunks) * 2 * A.L;
-                    hl[j] = p[0];
-                    hr[j] = p[A.L];
+                    hlr[j].x = p[0];
+                    hlr[j].y = p[A.L];
                 }
             }
         }
@@ -591,7 +592,8 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         for (int j = 0; j < HD_NX; ++j) {
             const int i4 = tid + j * HD_THREADS;
             f32x4 v = xv[j];
-            v = (4 * i4 >= x_lo && 4 * i4 < x_hi) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!x_inside)                                   // uniform: only windows that overlap an end of the signal
+                v = (4 * i4 >= x_lo && 4 * i4 < x_hi) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             if (i4 < nrows * 8) xs4[(i4 & 7) * HD_XR + (i4 >> 3)] = v;
         }
         if (FUSED) {
@@ -633,13 +635,15 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         } else if (tap < Lseg) {
             if (seg0 + tap >= A.L) {                         // taps >= L read as zero (only when L % 8 != 0)
 #pragma unroll
-                for (int j = 0; j <= HD_HALFSLOTS; ++j) hl[j] = hr[j] = 0.f;
+                for (int j = 0; j <= HD_HALFSLOTS; ++j) hlr[j] = f32x2{0.f, 0.f};
             }
-            f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tap;
+            f32x2 *dst = reinterpret_cast<f32x2 *>(hd) + 2 * (slot_a * (HD_SLOT / 4) + tap);
 #pragma unroll
             for (int j = 0; j < HD_HALFSLOTS; ++j) {
-                if (slot_a + j < slot_b)
-                    dst[j * (HD_SLOT / 4)] = f32x4{hl[j], hr[j], hl[j + 1] - hl[j], hr[j + 1] - hr[j]};
+                if (slot_a + j < slot_b) {                   // (h0_L, h0_R | d_L, d_R): two 8-byte halves, no repacking
+                    dst[j * (HD_SLOT / 2)] = hlr[j];
+                    dst[j * (HD_SLOT / 2) + 1] = hlr[j + 1] - hlr[j];
+                }
             }
         }
         __syncthreads();
