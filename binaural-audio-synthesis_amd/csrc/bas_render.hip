@@ -415,7 +415,8 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
 #define HD_XR (HD_ROWS + 1)                   // odd: conflict-free column-major image
 #define HD_NX ((HD_ROWS * 8 + HD_THREADS - 1) / HD_THREADS)     // float4 of x per thread (9)
 #define HD_SLOT (RT_SEG * 4 + 4)              // floats per chunk slot (+16 B: slots on distinct banks)
-#define HD_MAXSLOTS 20
+#define HD_MAXSLOTS 20                     // chunk slots for two workgroups per CU (and the fused staging)
+#define HD_LDS_MAXSLOTS 61                 // chunk slots (+1 for the fused h0) that fit 160 KB of LDS beside the x window
 #define HD_HALFSLOTS (HD_MAXSLOTS / 2)     // chunk slots staged by one half of the threads
 #define HD_X_FLOATS (8 * HD_XR * 4)
 
@@ -632,17 +633,47 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                     reinterpret_cast<f32x2 *>(p4)[1] = f32x2{b.x - a.x, b.y - a.y};
                 }
             }
-        } else if (tap < Lseg) {
-            if (seg0 + tap >= A.L) {                         // taps >= L read as zero (only when L % 8 != 0)
-#pragma unroll
-                for (int j = 0; j <= HD_HALFSLOTS; ++j) hlr[j] = f32x2{0.f, 0.f};
-            }
+        } else {
+            const bool beyond = seg0 + tap >= A.L;           // taps >= L read as zero (only when L % 8 != 0)
             f32x2 *dst = reinterpret_cast<f32x2 *>(hd) + 2 * (slot_a * (HD_SLOT / 4) + tap);
+            if (tap < Lseg) {
+                if (beyond) {
 #pragma unroll
-            for (int j = 0; j < HD_HALFSLOTS; ++j) {
-                if (slot_a + j < slot_b) {                   // (h0_L, h0_R | d_L, d_R): two 8-byte halves, no repacking
-                    dst[j * (HD_SLOT / 2)] = hlr[j];
-                    dst[j * (HD_SLOT / 2) + 1] = hlr[j + 1] - hlr[j];
+                    for (int j = 0; j <= HD_HALFSLOTS; ++j) hlr[j] = f32x2{0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < HD_HALFSLOTS; ++j) {
+                    if (slot_a + j < slot_b) {               // (h0_L, h0_R | d_L, d_R): two 8-byte halves, no repacking
+                        dst[j * (HD_SLOT / 2)] = hlr[j];
+                        dst[j * (HD_SLOT / 2) + 1] = hlr[j + 1] - hlr[j];
+                    }
+                }
+            }
+            // Small chunks (K < 448) put more than 2 x HD_HALFSLOTS chunk slots under a tile: the rest follow in
+            // further rounds of HD_HALFSLOTS per half.  Their loads are issued here, after the barrier, so their
+            // latency is exposed - the price of serving these shapes with this kernel instead of the generic one.
+            constexpr int XR = 5;                             // slots per extra round (few registers: rarely used path)
+            for (int base = HD_HALFSLOTS; slot_a + base < slot_b; base += XR) {      // uniform per wave
+                int k = seg0 + tap;
+                if (k > A.L - 1) k = A.L - 1;
+                const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
+                f32x2 more[XR + 1];
+#pragma unroll
+                for (int j = 0; j <= XR; ++j) {
+                    if (slot_a + base + j <= slot_b) {
+                        const float *p = Hk + (long)clampi(c0 + slot_a + base + j, 0, A.n_chunks) * 2 * A.L;
+                        more[j].x = beyond ? 0.f : p[0];
+                        more[j].y = beyond ? 0.f : p[A.L];
+                    }
+                }
+                if (tap < Lseg) {
+#pragma unroll
+                    for (int j = 0; j < XR; ++j) {
+                        if (slot_a + base + j < slot_b) {
+                            dst[(base + j) * (HD_SLOT / 2)] = more[j];
+                            dst[(base + j) * (HD_SLOT / 2) + 1] = more[j + 1] - more[j];
+                        }
+                    }
                 }
             }
         }
@@ -883,7 +914,11 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     if (!(aligned && n_src > 0 && T_in > 0 && (S % 32 == 0 || hd_small_s))) return p;
     const int hd_slots = (K - 32 + 32 * (HD_ROWS - 1)) / K + 1;
     const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
-    int kind = (s_pow2 && hd_slots <= HD_MAXSLOTS) ? KIND_HD : KIND_ROWS32;
+    // hd kernel: two workgroups per CU up to HD_MAXSLOTS chunk slots (K >= 448); with more slots (smaller chunks)
+    // its LDS image only fits once per CU: 1.07 ms vs 1.24 ms (rows32) at K = 256, S = 32, and 1.1 ms vs 32 ms
+    // (generic) at K = 256, S = 16, both on the 256-source scene
+    const bool hd_fits = s_pow2 && hd_slots <= HD_LDS_MAXSLOTS;
+    int kind = hd_fits ? KIND_HD : KIND_ROWS32;             // measured: hd at one workgroup per CU still beats rows32
     if (force && !strcmp(force, "rows32")) kind = KIND_ROWS32;
     if (kind == KIND_ROWS32 && S % 32 != 0) return p;        // small subchunks: hd kernel or nothing
     if (force && !strcmp(force, "generic")) return p;
@@ -974,7 +1009,7 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     (void)fused;
     const int live_src = T_in == 0 ? 0 : n_src;
     RenderPlan p = plan_render(live_src, T_in, K, S, L, aligned);
-    BAS_REQUIRE(!fused || live_src == 0 || p.kind == KIND_HD, BAS_E_SHAPE,
+    BAS_REQUIRE(!fused || live_src == 0 || (p.kind == KIND_HD && p.hd_slots <= HD_MAXSLOTS), BAS_E_SHAPE,
                 "bas_render_mix_fused_f32: sizes/alignment not served by the fused kernel "
                 "(bas_render_fused_supported); use bas_interp2d_f32 + bas_render_mix_f32");
     if (p.kind == KIND_GENERIC) {
@@ -1036,7 +1071,8 @@ extern "C" int bas_render_mix_profiled_f32(const float *x, long x_stride, const 
 
 extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L) {
     if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return 0;
-    return (S >= 32 && plan_render(n_src, T_in, K, S, L, true).kind == KIND_HD) ? 1 : 0;
+    const RenderPlan p = plan_render(n_src, T_in, K, S, L, true);
+    return (S >= 32 && p.kind == KIND_HD && p.hd_slots <= HD_MAXSLOTS) ? 1 : 0;
 }
 
 extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed, const void *plans,

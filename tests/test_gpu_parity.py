@@ -206,7 +206,13 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
                                                    ("", 2, 4000, 512, 32, 99),           # odd L
                                                    ("", 3, 9000, 512, 16, 128),          # hd kernel, 2 subchunks per row
                                                    ("", 3, 9000, 512, 8, 100),           # hd kernel, 4 subchunks per row
-                                                   ("", 2, 3000, 464, 16, 128)])         # K % 32 != 0: generic
+                                                   ("", 2, 3000, 464, 16, 128),          # K % 32 != 0: generic
+                                                   ("", 3, 20000, 256, 16, 128),         # hd, 34 chunk slots: extra staging rounds
+                                                   ("", 2, 20000, 160, 16, 100),         # hd, 53 chunk slots
+                                                   ("", 2, 20000, 192, 8, 128),          # hd, 4 subchunks per row, 45 slots
+                                                   ("", 2, 20000, 256, 32, 128),         # hd preferred over rows32
+                                                   ("rows32", 2, 20000, 256, 32, 128),
+                                                   ("", 2, 20000, 256, 64, 300)])        # three tap segments x 34 slots
 def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_src, n, k, s, l):
     """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL."""
     if force:
@@ -214,8 +220,8 @@ def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_sr
     name = bas._hip.lib().bas_render_kernel_name(n_src, -(-n // k) * k, k, s, l).decode()
     if force:
         assert force in name
-    if (l, "consistent") == (99, "consistent"):
-        h = tables["consistent"].truncated(99)
+    if ("consistent", l) not in dev_tables:
+        h = tables["consistent"].truncated(l)
         d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
     else:
         h, d = dev_tables[("consistent", l)]
@@ -247,6 +253,11 @@ def test_kernel_selection():
     lib = bas._hip.lib()
     assert lib.bas_render_kernel_name(256, 441344, 512, 32, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 128, 32, 128) == b"bas_render_rows32_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 256, 32, 128) == b"bas_render_hd_kernel"      # one workgroup per CU
+    assert lib.bas_render_kernel_name(256, 441344, 256, 16, 128) == b"bas_render_hd_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 128, 16, 128) == b"bas_render_generic_kernel"  # 66 chunk slots: no fit
+    assert lib.bas_render_kernel_name(256, 441600, 480, 96, 128) == b"bas_render_rows32_kernel"   # S not a power of two
+    assert lib.bas_render_fused_supported(256, 441344, 256, 32, 128) == 0                          # fused: K >= 448 only
     assert lib.bas_render_kernel_name(256, 441344, 128, 16, 128) == b"bas_render_generic_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 512, 16, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 512, 8, 128) == b"bas_render_hd_kernel"
