@@ -416,7 +416,6 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
 #define HD_NX ((HD_ROWS * 8 + HD_THREADS - 1) / HD_THREADS)     // float4 of x per thread (9)
 #define HD_SLOT (RT_SEG * 4 + 4)              // floats per chunk slot (+16 B: slots on distinct banks)
 #define HD_MAXSLOTS 20                     // chunk slots for two workgroups per CU (and the fused staging)
-#define HD_LDS_MAXSLOTS 61                 // chunk slots (+1 for the fused h0) that fit 160 KB of LDS beside the x window
 #define HD_HALFSLOTS (HD_MAXSLOTS / 2)     // chunk slots staged by one half of the threads
 #define HD_X_FLOATS (8 * HD_XR * 4)
 
@@ -428,9 +427,24 @@ __device__ __forceinline__ void hd_load_xrow(float (&xr)[32], const f32x4 *__res
     }
 }
 
+#define HO_SLOT (RT_SEG * 2 + 2)             // floats per chunk slot of the h-only image (+8 B: slots on distinct banks)
+
+// HONLY: the slot holds (h_L, h_R) only and d = H_{c+1} - H_c is taken here from the next slot (small chunks:
+// twice as many chunk slots fit the LDS; one more packed op per tap)
+template <bool HONLY>
 __device__ __forceinline__ void hd_load_octet(f32x4 (&hv)[8], const float *__restrict__ hdrow, int i) {
+    if (HONLY) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) hv[j] = *reinterpret_cast<const f32x4 *>(hdrow + (8 * i + j) * 4);
+        for (int j = 0; j < 8; ++j) {
+            const f32x2 h0 = *reinterpret_cast<const f32x2 *>(hdrow + (8 * i + j) * 2);
+            const f32x2 h1 = *reinterpret_cast<const f32x2 *>(hdrow + HO_SLOT + (8 * i + j) * 2);
+            const f32x2 d = h1 - h0;
+            hv[j] = f32x4{h0.x, h0.y, d.x, d.y};
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hv[j] = *reinterpret_cast<const f32x4 *>(hdrow + (8 * i + j) * 4);
+    }
 }
 
 // one octet of taps (delta = 8 i + j - 32 = output index - input index) against the whole input row.
@@ -458,7 +472,7 @@ __device__ __forceinline__ void hd_octet_fma(f32x2 (&acc)[32], const float (&xr)
 }
 
 // Row step with a run-time set of live octets (segments shorter than 128 taps, last row).
-template <int NSUB>
+template <int NSUB, bool HONLY = false>
 __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4 *__restrict__ xrow,
                                                     const float *__restrict__ hdrow, const float (&al)[NSUB],
                                                     unsigned live_mask) {
@@ -467,7 +481,7 @@ __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4
     f32x4 hv[8];
 #define HD_MASKED_OCTET(I)                          \
     if (live_mask & (1u << I)) {                    \
-        hd_load_octet(hv, hdrow, I);                \
+        hd_load_octet<HONLY>(hv, hdrow, I);         \
         hd_octet_fma<I, NSUB>(acc, xr, hv, al);     \
     }
     HD_MASKED_OCTET(0) HD_MASKED_OCTET(1) HD_MASKED_OCTET(2) HD_MASKED_OCTET(3)
@@ -475,8 +489,9 @@ __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4
 #undef HD_MASKED_OCTET
 }
 
-template <bool FUSED, int NSUB>
+template <bool FUSED, int NSUB, bool HONLY = false>
 __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs A, int nslots) {
+    static_assert(!(FUSED && HONLY), "the h-only image is staged from H");
     extern __shared__ f32x4 lds4[];
     f32x4 *xs4 = lds4;                                       // [8][HD_XR] float4
     float *hd = reinterpret_cast<float *>(lds4) + HD_X_FLOATS;   // [nslots][HD_SLOT]
@@ -558,8 +573,12 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         // slots from H.  Fused: wave wv evaluates rows (slot, ear) = wv, wv+4, .. of the nslots+1 chunk
         // IRs straight from the table through their read plans (one 128-byte plan per row, fetched now).
         const int tap = tid & (RT_SEG - 1);
-        const int slot_a = __builtin_amdgcn_readfirstlane(tid >> 7) * ((nslots + 1) >> 1);   // wave-uniform: scalar slot math
-        int slot_b = slot_a + ((nslots + 1) >> 1);
+        // (h0, d) image: a half stages slots [slot_a, slot_b) and needs H of slot_b too; h-only image: a half
+        // stages the H values [slot_a, slot_b] of the nslots + 1 chunk boundaries (slot_b inclusive = last - 1 + 1)
+        const int per_half = HONLY ? ((nslots + 2) >> 1) : ((nslots + 1) >> 1);
+        const int slot_a = __builtin_amdgcn_readfirstlane(tid >> 7) * per_half;   // wave-uniform: scalar slot math
+        int slot_b = slot_a + per_half;
+        if (HONLY) slot_b -= 1;                               // inclusive end of the values this half loads
         if (slot_b > nslots) slot_b = nslots;
         f32x2 hlr[HD_HALFSLOTS + 1];                         // (left, right) tap of the slots this thread stages
         constexpr int HD_MAXEVAL = (HD_MAXSLOTS + 1 + HD_NW - 1) / HD_NW;           // chunk IRs per wave
@@ -635,8 +654,36 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             }
         } else {
             const bool beyond = seg0 + tap >= A.L;           // taps >= L read as zero (only when L % 8 != 0)
-            f32x2 *dst = reinterpret_cast<f32x2 *>(hd) + 2 * (slot_a * (HD_SLOT / 4) + tap);
-            if (tap < Lseg) {
+            f32x2 *dst = reinterpret_cast<f32x2 *>(hd) + (HONLY ? slot_a * (HO_SLOT / 2) + tap
+                                                                 : 2 * (slot_a * (HD_SLOT / 4) + tap));
+            if (HONLY) {
+                // h-only image: plain copies of the H values slot_a .. slot_b, rounds of HD_HALFSLOTS + 1
+                if (tap < Lseg) {
+#pragma unroll
+                    for (int j = 0; j <= HD_HALFSLOTS; ++j)
+                        if (slot_a + j <= slot_b) dst[j * (HO_SLOT / 2)] = beyond ? f32x2{0.f, 0.f} : hlr[j];
+                }
+                constexpr int XH = 6;
+                for (int base = HD_HALFSLOTS + 1; slot_a + base <= slot_b; base += XH) {      // uniform per wave
+                    int k = seg0 + tap;
+                    if (k > A.L - 1) k = A.L - 1;
+                    const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
+                    f32x2 more[XH];
+#pragma unroll
+                    for (int j = 0; j < XH; ++j) {
+                        if (slot_a + base + j <= slot_b) {
+                            const float *p = Hk + (long)clampi(c0 + slot_a + base + j, 0, A.n_chunks) * 2 * A.L;
+                            more[j].x = beyond ? 0.f : p[0];
+                            more[j].y = beyond ? 0.f : p[A.L];
+                        }
+                    }
+                    if (tap < Lseg) {
+#pragma unroll
+                        for (int j = 0; j < XH; ++j)
+                            if (slot_a + base + j <= slot_b) dst[(base + j) * (HO_SLOT / 2)] = more[j];
+                    }
+                }
+            } else if (tap < Lseg) {
                 if (beyond) {
 #pragma unroll
                     for (int j = 0; j <= HD_HALFSLOTS; ++j) hlr[j] = f32x2{0.f, 0.f};
@@ -646,33 +693,6 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                     if (slot_a + j < slot_b) {               // (h0_L, h0_R | d_L, d_R): two 8-byte halves, no repacking
                         dst[j * (HD_SLOT / 2)] = hlr[j];
                         dst[j * (HD_SLOT / 2) + 1] = hlr[j + 1] - hlr[j];
-                    }
-                }
-            }
-            // Small chunks (K < 448) put more than 2 x HD_HALFSLOTS chunk slots under a tile: the rest follow in
-            // further rounds of HD_HALFSLOTS per half.  Their loads are issued here, after the barrier, so their
-            // latency is exposed - the price of serving these shapes with this kernel instead of the generic one.
-            constexpr int XR = 5;                             // slots per extra round (few registers: rarely used path)
-            for (int base = HD_HALFSLOTS; slot_a + base < slot_b; base += XR) {      // uniform per wave
-                int k = seg0 + tap;
-                if (k > A.L - 1) k = A.L - 1;
-                const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
-                f32x2 more[XR + 1];
-#pragma unroll
-                for (int j = 0; j <= XR; ++j) {
-                    if (slot_a + base + j <= slot_b) {
-                        const float *p = Hk + (long)clampi(c0 + slot_a + base + j, 0, A.n_chunks) * 2 * A.L;
-                        more[j].x = beyond ? 0.f : p[0];
-                        more[j].y = beyond ? 0.f : p[A.L];
-                    }
-                }
-                if (tap < Lseg) {
-#pragma unroll
-                    for (int j = 0; j < XR; ++j) {
-                        if (slot_a + base + j < slot_b) {
-                            dst[(base + j) * (HD_SLOT / 2)] = more[j];
-                            dst[(base + j) * (HD_SLOT / 2) + 1] = more[j + 1] - more[j];
-                        }
                     }
                 }
             }
@@ -702,7 +722,7 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
 #pragma unroll
                 for (int u = 0; u < NSUB; ++u) al[u] = (float)(m_in + u * (32 / NSUB)) * invK;   // S = 32 / NSUB
             }
-            hdrow = hd + sl * HD_SLOT + (32 * rp - 32) * 4;
+            hdrow = HONLY ? hd + sl * HO_SLOT + (32 * rp - 32) * 2 : hd + sl * HD_SLOT + (32 * rp - 32) * 4;
         };
         auto step_done = [&]() {
             xrow -= 1;
@@ -729,7 +749,7 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             float al[NSUB];
             const float *hdrow;
             step_setup(rp, al, hdrow);
-            hd_row_step_masked<NSUB>(acc, xrow, hdrow, al, mask_of(rp));
+            hd_row_step_masked<NSUB, HONLY>(acc, xrow, hdrow, al, mask_of(rp));
             step_done();
         }
 #ifdef BAS_STAMPS
@@ -901,6 +921,7 @@ struct RenderPlan {
     long n_tiles, units_total;
     int n_wg, units_per_wg, parts_per_wg;
     int hd_slots;              // chunk slots of the hd kernel
+    int honly;                 // 1: h-only LDS image (small chunks), see hd_load_octet
     size_t lds_bytes, slab_bytes;
 };
 
@@ -914,11 +935,13 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     if (!(aligned && n_src > 0 && T_in > 0 && (S % 32 == 0 || hd_small_s))) return p;
     const int hd_slots = (K - 32 + 32 * (HD_ROWS - 1)) / K + 1;
     const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
-    // hd kernel: two workgroups per CU up to HD_MAXSLOTS chunk slots (K >= 448); with more slots (smaller chunks)
-    // its LDS image only fits once per CU: 1.07 ms vs 1.24 ms (rows32) at K = 256, S = 32, and 1.1 ms vs 32 ms
-    // (generic) at K = 256, S = 16, both on the 256-source scene
-    const bool hd_fits = s_pow2 && hd_slots <= HD_LDS_MAXSLOTS;
-    int kind = hd_fits ? KIND_HD : KIND_ROWS32;             // measured: hd at one workgroup per CU still beats rows32
+    // hd kernel: up to HD_MAXSLOTS chunk slots per tile (K >= 448) the LDS image holds (h0, d) per tap; smaller
+    // chunks put more slots under a tile and use the h-only image (half the bytes per slot, d taken in the row
+    // step: two workgroups per CU down to K ~ 192, one below).  On the 256-source scene: 0.89 ms at K = 256,
+    // S = 32 (rows32: 1.24 ms), 0.93 ms at K = 256, S = 16 and 1.2 ms at K = 128, S = 16 (generic: 32 ms).
+    const bool hd_fits = s_pow2 && (hd_slots <= HD_MAXSLOTS ||
+                                    (size_t)(HD_X_FLOATS + (hd_slots + 1) * HO_SLOT) * sizeof(float) <= 160 * 1024);
+    int kind = hd_fits ? KIND_HD : KIND_ROWS32;
     if (force && !strcmp(force, "rows32")) kind = KIND_ROWS32;
     if (kind == KIND_ROWS32 && S % 32 != 0) return p;        // small subchunks: hd kernel or nothing
     if (force && !strcmp(force, "generic")) return p;
@@ -927,7 +950,9 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     if (kind == KIND_HD) {
         p.tile = HD_TILE;
         p.hd_slots = hd_slots;
-        p.lds_bytes = (size_t)(HD_X_FLOATS + (hd_slots + 1) * HD_SLOT) * sizeof(float);   // +1: fused h0 of the last chunk
+        p.honly = hd_slots > HD_MAXSLOTS;                   // measured faster than the full image at one workgroup per CU
+        p.lds_bytes = p.honly ? (size_t)(HD_X_FLOATS + (hd_slots + 1) * HO_SLOT) * sizeof(float)
+                              : (size_t)(HD_X_FLOATS + (hd_slots + 1) * HD_SLOT) * sizeof(float);   // +1: fused h0 of the last chunk
         wg_per_cu = (long)(160 * 1024 / p.lds_bytes);
         if (wg_per_cu > 2) wg_per_cu = 2;
         if (wg_per_cu < 1) wg_per_cu = 1;
@@ -1036,6 +1061,9 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     hd_fn hdk = fused ? bas_render_hd_kernel<true, 1>
                       : (nsub == 1 ? bas_render_hd_kernel<false, 1>
                                    : (nsub == 2 ? bas_render_hd_kernel<false, 2> : bas_render_hd_kernel<false, 4>));
+    if (p.kind == KIND_HD && p.honly)
+        hdk = nsub == 1 ? bas_render_hd_kernel<false, 1, true>
+                        : (nsub == 2 ? bas_render_hd_kernel<false, 2, true> : bas_render_hd_kernel<false, 4, true>);
     const void *fn = p.kind == KIND_HD ? reinterpret_cast<const void *>(hdk)
                                         : reinterpret_cast<const void *>(bas_render_rows32_kernel);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);

@@ -201,7 +201,11 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
 @pytest.mark.parametrize("force,n_src,n,k,s,l", [("rows32", 4, 9000, 512, 32, 128),   # forced fallback kernel
                                                    ("rows32", 3, 6000, 512, 64, 100),
                                                    ("generic", 2, 3000, 512, 32, 128),
-                                                   ("", 3, 5000, 128, 32, 128),          # K < 448: rows32 by itself
+                                                   ("", 3, 20000, 128, 32, 128),         # hd, h-only LDS image (66 slots)
+                                                   ("", 2, 20000, 128, 16, 100),         # the reference golden's shape
+                                                   ("", 2, 20000, 96, 8, 128),           # 88 slots, 4 subchunks per row
+                                                   ("", 2, 20000, 128, 128, 300),        # h-only, three tap segments
+                                                   ("", 3, 5000, 64, 32, 128),           # K = 64: rows32 by itself
                                                    ("", 3, 5000, 1024, 256, 128),        # hd kernel, S > 32
                                                    ("", 2, 4000, 512, 32, 99),           # odd L
                                                    ("", 3, 9000, 512, 16, 128),          # hd kernel, 2 subchunks per row
@@ -252,13 +256,14 @@ def test_fused_render_equals_unfused(dev_tables, tables, n_src, n, k, s, l):
 def test_kernel_selection():
     lib = bas._hip.lib()
     assert lib.bas_render_kernel_name(256, 441344, 512, 32, 128) == b"bas_render_hd_kernel"
-    assert lib.bas_render_kernel_name(256, 441344, 128, 32, 128) == b"bas_render_rows32_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 256, 32, 128) == b"bas_render_hd_kernel"      # one workgroup per CU
     assert lib.bas_render_kernel_name(256, 441344, 256, 16, 128) == b"bas_render_hd_kernel"
-    assert lib.bas_render_kernel_name(256, 441344, 128, 16, 128) == b"bas_render_generic_kernel"  # 66 chunk slots: no fit
+    assert lib.bas_render_kernel_name(256, 441344, 128, 32, 128) == b"bas_render_hd_kernel"      # h-only LDS image
+    assert lib.bas_render_kernel_name(256, 441344, 128, 16, 128) == b"bas_render_hd_kernel"
+    assert lib.bas_render_kernel_name(256, 441344, 64, 32, 128) == b"bas_render_rows32_kernel"    # 131 chunk slots: no fit
+    assert lib.bas_render_kernel_name(256, 441344, 64, 16, 128) == b"bas_render_generic_kernel"
     assert lib.bas_render_kernel_name(256, 441600, 480, 96, 128) == b"bas_render_rows32_kernel"   # S not a power of two
     assert lib.bas_render_fused_supported(256, 441344, 256, 32, 128) == 0                          # fused: K >= 448 only
-    assert lib.bas_render_kernel_name(256, 441344, 128, 16, 128) == b"bas_render_generic_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 512, 16, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 512, 8, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 464, 16, 128) == b"bas_render_generic_kernel"
