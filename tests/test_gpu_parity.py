@@ -705,3 +705,42 @@ def test_random_shape_sweep(tables):
             fz = bas.render_sources(sigs, k, s_, elev, azim, d, normalize="none", fused=True).cpu().numpy()
             assert rel_err(fz, want) <= REL, (case, "fused", l, k, s_)
     assert seen == {"bas_render_hd_kernel", "bas_render_rows32_kernel", "bas_render_generic_kernel"}, seen
+
+
+@pytest.mark.parametrize("k,s", [(512, 32), (480, 96), (464, 16), (128, 16)])     # hd, rows32, generic, hd h-only
+def test_accumulate_into_existing_mix(dev_tables, k, s):
+    """bas_render_mix_f32 with accumulate != 0 adds into y (include/bas.h) and reports the peak of the sum:
+    rendering sources in two calls equals rendering them in one."""
+    import torch
+    h, d = dev_tables[("consistent", 128)]
+    n_src, n = 5, 12000
+    sigs, elev, azim, _ = _mix_case(h, n_src, n, k, s, seed=900)
+    in_length, _ = orc.render_lengths(n, k, 128)
+    x = torch.zeros((n_src, in_length), dtype=torch.float32, device="cuda")
+    x[:, :n] = torch.from_numpy(sigs).float().cuda()
+    idx, w = bas.sphere.interpolation_params_batch(elev, azim)
+    H = bas.interpolate_2d_params(d, idx.reshape(-1, 4), w.reshape(-1, 3)).view(n_src, -1, 2, 128)
+    whole, peak_whole = bas.apply_hrtf.render_device(x, k, s, H, 128, normalize="none")
+    y, _ = bas.apply_hrtf.render_device(x[:2], k, s, H[:2].contiguous(), 128, normalize="none")
+    y2, peak2 = bas.apply_hrtf.render_device(x[2:], k, s, H[2:].contiguous(), 128, normalize="none", out=y, accumulate=True)
+    assert y2.data_ptr() == y.data_ptr()
+    scale = float(whole.abs().max())
+    assert float((y - whole).abs().max()) / scale <= 2e-6
+    assert abs(float(peak2) - float(y.abs().max())) <= 1e-6 * scale and abs(float(peak_whole) - scale) <= 1e-6 * scale
+
+
+def test_peak_normalize_entry_point():
+    """bas_peak_normalize_f32 (apply_hrtf.py:462-464): measure only, then measure + scale; quiet signals stay."""
+    import torch
+    from binaural_audio_synthesis_amd import _hip
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for amp in (0.3, 2.5):
+        y = (torch.rand(100003, generator=gen, device="cuda") * 2 - 1) * amp
+        y0 = y.clone()
+        peak = torch.empty(1, dtype=torch.float32, device="cuda")
+        _hip.call("bas_peak_normalize_f32", _hip.ptr(y), y.numel(), _hip.ptr(peak), 0, _hip.current_stream(y.device))
+        m = float(y0.abs().max())
+        assert float(peak) == m and torch.equal(y, y0)
+        _hip.call("bas_peak_normalize_f32", _hip.ptr(y), y.numel(), _hip.ptr(peak), 1, _hip.current_stream(y.device))
+        want = y0 / m if m > 1 else y0
+        assert float((y - want).abs().max()) <= 1e-7 * max(m, 1.0) and float(peak) == m
