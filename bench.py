@@ -292,11 +292,19 @@ def main():
 
     fused = os.environ.get("BAS_BENCH_FUSED", "0") == "1"   # chunk IRs inside the FIR kernel (bas_render_mix_fused_f32)
 
-    def step(i_event=None):
+    def render_into(y_buf, i_event):
         events = None if i_event is None else ev.pairs[i_event]
-        _, pk = bas.apply_hrtf.render_params_device(x, k, s, tbl, idx, w, normalize="none", out=y, events=events,
-                                                    ws=ws, ws_plans=ws_i, fused=fused)
+        return bas.apply_hrtf.render_params_device(x, k, s, tbl, idx, w, normalize="none", out=y_buf, events=events,
+                                                   ws=ws, ws_plans=ws_i, fused=fused)[1]
+
+    def mix_on_root(parts_buf):
         stream = _hip.current_stream(dev)
+        _hip.call("bas_mix_partials_f32", _hip.ptr(parts_buf), world, 2 * t_out, 2 * t_out, _hip.ptr(y_final),
+                  _hip.ptr(peak), stream)
+        _hip.call("bas_scale_by_peak_f32", _hip.ptr(y_final), 2 * t_out, _hip.ptr(peak), stream)
+
+    def step_sync(i_event=None):
+        pk = render_into(y, i_event)
         if world > 1 and backend != "nccl":              # rehearsal only: gather through host memory
             y_host = y.cpu()
             if rank == 0:
@@ -309,13 +317,59 @@ def main():
             dist.gather(y, gather_list=list(parts.unbind(0)) if rank == 0 else None, dst=0)
         if world > 1:
             if rank == 0:
-                _hip.call("bas_mix_partials_f32", _hip.ptr(parts), world, 2 * t_out, 2 * t_out, _hip.ptr(y_final),
-                          _hip.ptr(peak), stream)
-                _hip.call("bas_scale_by_peak_f32", _hip.ptr(y_final), 2 * t_out, _hip.ptr(peak), stream)
+                mix_on_root(parts)
         else:
-            _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(pk), stream)
+            _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(pk), _hip.current_stream(dev))
+
+    # N > 1: the gather of step i travels (RCCL stream, xGMI) while step i+1 renders; y and the root's receive
+    # buffer are double-buffered, the root sums step i right after it has launched step i+1's gather.  Every
+    # collective is issued by all ranks in step order; drain() inside the timed region completes the last one.
+    # BAS_BENCH_SYNC_GATHER=1 restores gather-then-continue.
+    overlap = world > 1 and os.environ.get("BAS_BENCH_SYNC_GATHER", "0") != "1"
+    ys = [y, torch.empty_like(y)] if overlap else [y]
+    parts2 = [parts, torch.empty_like(parts)] if (overlap and rank == 0) else [parts]
+    inflight = [None, None]
+    counter = [0]
+
+    def launch_gather(b):
+        if backend == "nccl":
+            work = dist.gather(ys[b], gather_list=list(parts2[b].unbind(0)) if rank == 0 else None, dst=0,
+                               async_op=True)
+            return (work, None, None)
+        y_host = ys[b].cpu()                              # rehearsal only: gloo moves host memory
+        host_parts = [torch.empty_like(y_host) for _ in range(world)] if rank == 0 else None
+        return (dist.gather(y_host, gather_list=host_parts, dst=0, async_op=True), host_parts, y_host)
+
+    def finish_gather(b):
+        if inflight[b] is None:
+            return
+        work, host_parts, _ = inflight[b]
+        work.wait()                                       # nccl: the current stream waits, the host does not
+        if rank == 0:
+            if host_parts is not None:
+                parts2[b].copy_(torch.stack(host_parts))
+            mix_on_root(parts2[b])
+        inflight[b] = None
+
+    def step_overlapped(i_event=None):
+        b = counter[0] & 1
+        counter[0] += 1
+        finish_gather(b)                                  # the collective that read ys[b] two steps ago is done
+        render_into(ys[b], i_event)
+        inflight[b] = launch_gather(b)
+        if rank == 0:
+            finish_gather(b ^ 1)                          # previous step: its gather ran beside this render
+
+    def drain():
+        if overlap:
+            b = counter[0] & 1
+            finish_gather(b)                              # older one first
+            finish_gather(b ^ 1)
+
+    step = step_overlapped if overlap else step_sync
 
     def fence():
+        drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -333,6 +387,13 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    if overlap and os.environ.get("BAS_BENCH_CHECK") == "1":   # rehearsal: the pipelined mix equals the synchronous one
+        pipelined = y_final.clone() if rank == 0 else None
+        step_sync()
+        torch.cuda.synchronize(dev)
+        if rank == 0:
+            assert torch.equal(pipelined, y_final), "overlapped gather changed the mix"
+            print("check: pipelined mix == synchronous mix", file=sys.stderr, flush=True)
 
     fir_ms = [ev.elapsed_ms(i) for i in range(args.steps)]
     fir_avg_s = sum(fir_ms) / len(fir_ms) / 1e3
@@ -363,7 +424,8 @@ def main():
                                    f"-> 1 stereo mix; chunk {k}, subchunk {s}, {l}-tap HRIRs (U=8, 187 directions), "
                                    f"spiral/askew-circle trajectories; scene = {total_src} sources on {world} GPU(s)",
                        "sources_per_gpu": n_src, "samples_per_source": n, "chunk": k, "subchunk": s, "taps": l,
-                       "out_samples": t_out, "parallelism": f"sources sharded over {world} GPU(s), 1 gather"},
+                       "out_samples": t_out, "parallelism": f"sources sharded over {world} GPU(s), 1 gather per step" +
+                                                      (", travelling beside the next step's render" if overlap else "")},
             "x_realtime": (n / FS) * scenes / (elapsed / args.steps),
             "source_samples_per_s": total_src * in_length * args.steps / elapsed,
             "roofline": {"bound": "hbm", "achieved": algo_bytes / fir_avg_s / 1e9, "peak": HBM_PEAK_GBS,
