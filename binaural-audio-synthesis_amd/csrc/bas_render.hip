@@ -471,13 +471,10 @@ __device__ __forceinline__ void hd_octet_fma(f32x2 (&acc)[32], const float (&xr)
     }
 }
 
-// Row step with a run-time set of live octets (segments shorter than 128 taps, last row).
-template <int NSUB, bool HONLY = false>
-__device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4 *__restrict__ xrow,
-                                                    const float *__restrict__ hdrow, const float (&al)[NSUB],
-                                                    unsigned live_mask) {
-    float xr[32];
-    hd_load_xrow(xr, xrow);
+// Row step on an x row already in registers, with a run-time set of live octets.
+template <int NSUB, bool HONLY>
+__device__ __forceinline__ void hd_row_step_x(f32x2 (&acc)[32], const float (&xr)[32], const float *__restrict__ hdrow,
+                                               const float (&al)[NSUB], unsigned live_mask) {
     f32x4 hv[8];
 #define HD_MASKED_OCTET(I)                          \
     if (live_mask & (1u << I)) {                    \
@@ -489,9 +486,24 @@ __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4
 #undef HD_MASKED_OCTET
 }
 
-template <bool FUSED, int NSUB, bool HONLY = false>
+// Row step with a run-time set of live octets (segments shorter than 128 taps, last row).
+template <int NSUB, bool HONLY = false>
+__device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4 *__restrict__ xrow,
+                                                    const float *__restrict__ hdrow, const float (&al)[NSUB],
+                                                    unsigned live_mask) {
+    float xr[32];
+    hd_load_xrow(xr, xrow);
+    hd_row_step_x<NSUB, HONLY>(acc, xr, hdrow, al, live_mask);
+}
+
+// DUAL: any chunk size (multiple of 4) and any subchunk size >= 32.  A row of 32 inputs then meets at most one
+// subchunk (or chunk) boundary, at an input p that differs from lane to lane: the row step runs once on the
+// inputs before p with their (slot, alpha) and once more on the rest with the next subchunk's - twice the FMAs,
+// still an order of magnitude ahead of the generic kernel.
+template <bool FUSED, int NSUB, bool HONLY = false, bool DUAL = false>
 __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs A, int nslots) {
     static_assert(!(FUSED && HONLY), "the h-only image is staged from H");
+    static_assert(!DUAL || (NSUB == 1 && !FUSED), "dual rows: subchunks of at least 32 samples, unfused");
     extern __shared__ f32x4 lds4[];
     f32x4 *xs4 = lds4;                                       // [8][HD_XR] float4
     float *hd = reinterpret_cast<float *>(lds4) + HD_X_FLOATS;   // [nslots][HD_SLOT]
@@ -745,12 +757,42 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             if ((t & 1u) ^ prio_flip) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
         }
-        for (int rp = 0; rp <= halo; ++rp) {
-            float al[NSUB];
-            const float *hdrow;
-            step_setup(rp, al, hdrow);
-            hd_row_step_masked<NSUB, HONLY>(acc, xrow, hdrow, al, mask_of(rp));
-            step_done();
+        if (DUAL) {
+            const float invS = 1.0f / (float)A.S;
+            for (int rp = 0; rp <= halo; ++rp) {
+                // subchunk of the row's first input: q = m_in / S (float estimate, corrected), r = m_in % S
+                int q = (int)((float)m_in * invS);
+                int r = m_in - q * A.S;
+                if (r < 0) { q -= 1; r += A.S; }
+                if (r >= A.S) { q += 1; r -= A.S; }
+                const int p = A.S - r;                       // inputs [0, p) of the row lie in that subchunk (p > 32: all)
+                const int j_next = (q + 1) * A.S;            // start of the next subchunk inside the chunk
+                const bool wraps = j_next >= A.K;            // ... or the first subchunk of the next chunk
+                const int tap_off = (32 * rp - 32) * (HONLY ? 2 : 4);
+                const int slot_f = HONLY ? HO_SLOT : HD_SLOT;
+                float xa[32];
+                hd_load_xrow(xa, xrow);
+#pragma unroll
+                for (int a = 0; a < 32; ++a) xa[a] = a < p ? xa[a] : 0.f;
+                float al[1] = {(float)(q * A.S) * invK};
+                hd_row_step_x<1, HONLY>(acc, xa, hd + sl * slot_f + tap_off, al, mask_of(rp));
+                if (__any(p < 32)) {                         // some row of this wave meets a boundary
+                    hd_load_xrow(xa, xrow);                  // read again rather than hold 32 more registers
+#pragma unroll
+                    for (int a = 0; a < 32; ++a) xa[a] = a < p ? 0.f : xa[a];
+                    float al2[1] = {wraps ? 0.f : (float)j_next * invK};
+                    hd_row_step_x<1, HONLY>(acc, xa, hd + (sl + (wraps ? 1 : 0)) * slot_f + tap_off, al2, mask_of(rp));
+                }
+                step_done();
+            }
+        } else {
+            for (int rp = 0; rp <= halo; ++rp) {
+                float al[NSUB];
+                const float *hdrow;
+                step_setup(rp, al, hdrow);
+                hd_row_step_masked<NSUB, HONLY>(acc, xrow, hdrow, al, mask_of(rp));
+                step_done();
+            }
         }
 #ifdef BAS_STAMPS
         st_fir += __builtin_amdgcn_s_memrealtime() - tf0;
@@ -922,6 +964,7 @@ struct RenderPlan {
     int n_wg, units_per_wg, parts_per_wg;
     int hd_slots;              // chunk slots of the hd kernel
     int honly;                 // 1: h-only LDS image (small chunks), see hd_load_octet
+    int dual;                  // 1: dual row step (subchunk size not a power of two / multiple of 32)
     size_t lds_bytes, slab_bytes;
 };
 
@@ -932,9 +975,37 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     p.kind = KIND_GENERIC;
     const bool s_pow2 = (S & (S - 1)) == 0;
     const bool hd_small_s = s_pow2 && (S == 16 || S == 8) && K % 32 == 0;     // rows of 32 hold 2 / 4 subchunks
-    if (!(aligned && n_src > 0 && T_in > 0 && (S % 32 == 0 || hd_small_s))) return p;
-    const int hd_slots = (K - 32 + 32 * (HD_ROWS - 1)) / K + 1;
     const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
+    if (!(aligned && n_src > 0 && T_in > 0)) return p;
+    if (!(S % 32 == 0 || hd_small_s)) {
+        // Any other subchunk size >= 32 (and chunk size a multiple of 4, so that rows stay 16-byte aligned): the
+        // hd kernel's dual row step.  One slot more than the rows reach: the part of a row behind a chunk
+        // boundary reads the next chunk's slot.
+        const int dual_slots = (K - 1 + 32 * (HD_ROWS - 1) + 31) / K + 2;
+        const bool full = dual_slots <= HD_MAXSLOTS;
+        const size_t lds = full ? (size_t)(HD_X_FLOATS + (dual_slots + 1) * HD_SLOT) * sizeof(float)
+                                : (size_t)(HD_X_FLOATS + (dual_slots + 1) * HO_SLOT) * sizeof(float);
+        if (S < 32 || K % 4 != 0 || lds > 160 * 1024 || (force && strcmp(force, "hd"))) return p;
+        p.kind = KIND_HD;
+        p.dual = 1;
+        p.honly = !full;
+        p.hd_slots = dual_slots;
+        p.tile = HD_TILE;
+        p.lds_bytes = lds;
+        long wg_per_cu = (long)(160 * 1024 / lds);
+        wg_per_cu = wg_per_cu > 2 ? 2 : (wg_per_cu < 1 ? 1 : wg_per_cu);
+        const long T_out = T_in + L - 1;
+        p.n_tiles = (T_out + p.tile - 1) / p.tile;
+        p.units_total = p.n_tiles * n_src;
+        long slots = wg_per_cu * device_cus();
+        long wg = p.units_total < slots ? p.units_total : slots;
+        p.units_per_wg = (int)((p.units_total + wg - 1) / wg);
+        p.n_wg = (int)((p.units_total + p.units_per_wg - 1) / p.units_per_wg);
+        p.parts_per_wg = (p.units_per_wg + n_src - 2) / n_src + 1;
+        p.slab_bytes = (size_t)p.n_wg * p.parts_per_wg * 2 * p.tile * sizeof(float);
+        return p;
+    }
+    const int hd_slots = (K - 32 + 32 * (HD_ROWS - 1)) / K + 1;
     // hd kernel: up to HD_MAXSLOTS chunk slots per tile (K >= 448) the LDS image holds (h0, d) per tap; smaller
     // chunks put more slots under a tile and use the h-only image (half the bytes per slot, d taken in the row
     // step: two workgroups per CU down to K ~ 192, one below).  On the 256-source scene: 0.89 ms at K = 256,
@@ -1034,7 +1105,7 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     (void)fused;
     const int live_src = T_in == 0 ? 0 : n_src;
     RenderPlan p = plan_render(live_src, T_in, K, S, L, aligned);
-    BAS_REQUIRE(!fused || live_src == 0 || (p.kind == KIND_HD && p.hd_slots <= HD_MAXSLOTS), BAS_E_SHAPE,
+    BAS_REQUIRE(!fused || live_src == 0 || (p.kind == KIND_HD && p.hd_slots <= HD_MAXSLOTS && !p.dual), BAS_E_SHAPE,
                 "bas_render_mix_fused_f32: sizes/alignment not served by the fused kernel "
                 "(bas_render_fused_supported); use bas_interp2d_f32 + bas_render_mix_f32");
     if (p.kind == KIND_GENERIC) {
@@ -1061,7 +1132,9 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     hd_fn hdk = fused ? bas_render_hd_kernel<true, 1>
                       : (nsub == 1 ? bas_render_hd_kernel<false, 1>
                                    : (nsub == 2 ? bas_render_hd_kernel<false, 2> : bas_render_hd_kernel<false, 4>));
-    if (p.kind == KIND_HD && p.honly)
+    if (p.kind == KIND_HD && p.dual)
+        hdk = p.honly ? bas_render_hd_kernel<false, 1, true, true> : bas_render_hd_kernel<false, 1, false, true>;
+    else if (p.kind == KIND_HD && p.honly)
         hdk = nsub == 1 ? bas_render_hd_kernel<false, 1, true>
                         : (nsub == 2 ? bas_render_hd_kernel<false, 2, true> : bas_render_hd_kernel<false, 4, true>);
     const void *fn = p.kind == KIND_HD ? reinterpret_cast<const void *>(hdk)
@@ -1100,7 +1173,7 @@ extern "C" int bas_render_mix_profiled_f32(const float *x, long x_stride, const 
 extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L) {
     if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return 0;
     const RenderPlan p = plan_render(n_src, T_in, K, S, L, true);
-    return (S >= 32 && p.kind == KIND_HD && p.hd_slots <= HD_MAXSLOTS) ? 1 : 0;
+    return (S >= 32 && p.kind == KIND_HD && p.hd_slots <= HD_MAXSLOTS && !p.dual) ? 1 : 0;
 }
 
 extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed, const void *plans,
