@@ -194,6 +194,14 @@ def interpolate_2d_deg(irs_and_delaydiffs, elev, azim):
 # --------------------------------------------------------------------------
 # a7
 # --------------------------------------------------------------------------
+def padded_rows(n_rows, length, device):
+    """Zero-filled float32 [n_rows, length] whose rows start 16-byte aligned (row stride rounded up to a
+    multiple of 4 floats): what the fast FIR kernels want when the padded signal length is not a multiple of 4."""
+    import torch
+    stride = (length + 3) // 4 * 4
+    return torch.zeros((n_rows, stride), dtype=torch.float32, device=device)[:, :length]
+
+
 def render_lengths(n, chunksize, ir_length):
     in_length = int(0.5 + math.ceil(n / chunksize) * chunksize)             # :405
     return in_length, in_length + ir_length - 1                             # :410
@@ -298,7 +306,7 @@ def render_sources(signals, chunksize, subchunksize, elev, azim, tbl, normalize=
     assert sig.dim() == 2, 'signals must be [n_src, N]'
     n_src, n = sig.shape
     in_length, _ = render_lengths(n, chunksize, tbl.L)
-    x = torch.zeros((n_src, in_length), dtype=torch.float32, device=dev)    # :406
+    x = padded_rows(n_src, in_length, dev)                                   # :406
     x[:, :n] = sig.to(device=dev, dtype=torch.float32)
     n_q = in_length // chunksize + 1
     idx, w = sphere.interpolation_params_batch(elev, azim)
@@ -347,7 +355,7 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
             idx[i], w[i] = sphere.interpolation_params(*elev_azim_function(t))
             if verbose:
                 print(' {:.1f}%           '.format(100 * t / max(in_length, 1)), end='\r')
-    x = torch.zeros((1, in_length), dtype=torch.float32, device=dev)         # :405-406
+    x = padded_rows(1, in_length, dev)                                       # :405-406
     src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
     x[0, :n] = src.to(device=dev, dtype=torch.float32)
     idx_t, w_t = _params_to_device(tbl, idx, w)
@@ -392,7 +400,7 @@ def make_signal_move(in_signal, chunksize: int, index_function, irs_and_delaydif
     H = torch.empty((1, n_chunks + 1, 2, tbl.L), dtype=torch.float32, device=dev)
     _hip.call("bas_ring_interp_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(pq_t), _hip.ptr(al_t),
               n_chunks + 1, tbl.ndir, tbl.L, tbl.upsampling, 0, _hip.ptr(H), None, _hip.current_stream(dev))
-    x = torch.zeros((1, in_length), dtype=torch.float32, device=dev)         # :309-310
+    x = padded_rows(1, in_length, dev)                                       # :309-310
     src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
     x[0, :n] = src.to(device=dev, dtype=torch.float32)
     y, _ = render_device(x, int(chunksize), int(chunksize), H, tbl.L, "mix")

@@ -573,12 +573,15 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         const int x_lo = lo_l < -(1 << 30) ? -(1 << 30) : (lo_l > (1 << 30) ? (1 << 30) : (int)lo_l);
         const int x_hi = hi_l < -(1 << 30) ? -(1 << 30) : (hi_l > (1 << 30) ? (1 << 30) : (int)hi_l);
         const bool x_inside = x_lo <= 0 && x_hi >= 4 * HD_NX * HD_THREADS;   // whole window inside the signal
+        // T_in % 4 != 0 (dual rows, odd chunk sizes): the float4 that straddles the signal's end is read whole -
+        // the row stride is a multiple of 4, so the floats exist - and masked element by element below
+        const int x_hi4 = (x_hi + 3) & ~3;
         f32x4 xv[HD_NX];
 #pragma unroll
         for (int j = 0; j < HD_NX; ++j) {
             int i = 4 * (tid + j * HD_THREADS);
             i = i < x_lo ? x_lo : i;
-            i = i > x_hi - 4 ? x_hi - 4 : i;                 // clamped into the row (x_hi - 4 >= x_lo as T_in >= 4)
+            i = i > x_hi4 - 4 ? x_hi4 - 4 : i;               // clamped into the row (x_hi4 - 4 >= x_lo as T_in >= 1)
             xv[j] = *reinterpret_cast<const f32x4 *>(xwin + i);
         }
         // chunk IRs.  Unfused: thread = (tap, half), each half of the threads stages half of the chunk
@@ -625,7 +628,14 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             const int i4 = tid + j * HD_THREADS;
             f32x4 v = xv[j];
             if (!x_inside)                                   // uniform: only windows that overlap an end of the signal
-                v = (4 * i4 >= x_lo && 4 * i4 < x_hi) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            {
+                const int e = 4 * i4;                        // x_lo is a multiple of 4: one lower test for all four
+                const bool lo_ok = e >= x_lo;
+                v.x = (lo_ok && e < x_hi) ? v.x : 0.f;
+                v.y = (lo_ok && e + 1 < x_hi) ? v.y : 0.f;
+                v.z = (lo_ok && e + 2 < x_hi) ? v.z : 0.f;
+                v.w = (lo_ok && e + 3 < x_hi) ? v.w : 0.f;
+            }
             if (i4 < nrows * 8) xs4[(i4 & 7) * HD_XR + (i4 >> 3)] = v;
         }
         if (FUSED) {
@@ -978,14 +988,14 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
     if (!(aligned && n_src > 0 && T_in > 0)) return p;
     if (!(S % 32 == 0 || hd_small_s)) {
-        // Any other subchunk size >= 32 (and chunk size a multiple of 4, so that rows stay 16-byte aligned): the
+        // Any other subchunk size >= 32 (any chunk size; the caller keeps rows 16-byte aligned through x_stride): the
         // hd kernel's dual row step.  One slot more than the rows reach: the part of a row behind a chunk
         // boundary reads the next chunk's slot.
         const int dual_slots = (K - 1 + 32 * (HD_ROWS - 1) + 31) / K + 2;
         const bool full = dual_slots <= HD_MAXSLOTS;
         const size_t lds = full ? (size_t)(HD_X_FLOATS + (dual_slots + 1) * HD_SLOT) * sizeof(float)
                                 : (size_t)(HD_X_FLOATS + (dual_slots + 1) * HO_SLOT) * sizeof(float);
-        if (S < 32 || K % 4 != 0 || lds > 160 * 1024 || (force && strcmp(force, "hd"))) return p;
+        if (S < 32 || lds > 160 * 1024 || (force && strcmp(force, "hd"))) return p;
         p.kind = KIND_HD;
         p.dual = 1;
         p.honly = !full;

@@ -42,7 +42,7 @@ class StreamRenderer:
         import torch
         cap = self._xbuf.shape[1] - self.halo
         if cap < B:
-            grown = torch.zeros((self.n_src, self.halo + (B + 3) // 4 * 4), dtype=torch.float32, device=self._xbuf.device)
+            grown = torch.zeros((self.n_src, (self.halo + B + 3) // 4 * 4), dtype=torch.float32, device=self._xbuf.device)
             grown[:, :self.halo] = self._xbuf[:, :self.halo]
             self._xbuf = grown
 

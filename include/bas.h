@@ -116,7 +116,10 @@ int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *id
  * i.e. per-subchunk crossfaded IR, direct-form FIR (what scipy.signal.convolve
  * resolves to at these sizes), overlap-add, summed over sources.
  *   x  [n_src] rows of T_in floats, row stride x_stride floats; T_in % K == 0
- *      (the caller zero-pads as apply_hrtf.py:405-406 does)
+ *      (the caller zero-pads as apply_hrtf.py:405-406 does).  The fast kernels need x 16-byte
+ *      aligned and x_stride % 4 == 0 (else the plain kernel runs); when T_in % 4 != 0 they read
+ *      every row up to the next multiple of 4 floats, which x_stride then covers - also for
+ *      the last row, so allocate n_src * x_stride floats.
  *   H  [n_src][T_in/K + 1][2][L] f32 (bas_interp2d_f32 output, chunk IRs at
  *      t = 0, K, .., T_in; :429, :435)
  *   y  [2][T_in + L - 1] f32; overwritten, or added to when accumulate != 0

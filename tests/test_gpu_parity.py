@@ -222,6 +222,8 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
                                                    ("", 2, 20000, 500, 50, 128),
                                                    ("", 2, 20000, 300, 60, 300),         # dual + h-only image + 3 tap segments
                                                    ("", 2, 20000, 96, 48, 128),          # dual, 90 slots
+                                                   ("", 2, 20000, 250, 50, 128),         # dual, T_in % 4 != 0 (padded row stride)
+                                                   ("", 3, 20001, 333, 37, 100),         # odd everything
                                                    ("", 2, 9000, 36, 36, 128)])          # image does not fit: generic
 def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_src, n, k, s, l):
     """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL."""
@@ -272,7 +274,7 @@ def test_kernel_selection():
     assert lib.bas_render_kernel_name(256, 441000, 1000, 100, 128) == b"bas_render_hd_kernel"     # dual row step
     assert lib.bas_render_kernel_name(256, 441000, 1000, 50, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441000, 1000, 25, 128) == b"bas_render_generic_kernel"  # S < 32, not 8 / 16
-    assert lib.bas_render_kernel_name(256, 441090, 490, 49, 128) == b"bas_render_generic_kernel"   # K % 4 != 0
+    assert lib.bas_render_kernel_name(256, 441090, 490, 49, 128) == b"bas_render_hd_kernel"        # any chunk size
     assert lib.bas_render_fused_supported(256, 441000, 1000, 100, 128) == 0
     assert lib.bas_render_fused_supported(256, 441344, 256, 32, 128) == 0                          # fused: K >= 448 only
     assert lib.bas_render_kernel_name(256, 441344, 512, 16, 128) == b"bas_render_hd_kernel"
