@@ -453,20 +453,40 @@ __device__ __forceinline__ void hd_load_octet(f32x4 (&hv)[8], const float *__res
 template <int I, int NSUB>
 __device__ __forceinline__ void hd_octet_fma(f32x2 (&acc)[32], const float (&xr)[32], const f32x4 (&hv)[8],
                                               const float (&al)[NSUB]) {
-    f32x2 g[NSUB][8];
+    constexpr int G = 32 / NSUB;                 // inputs per group (= the subchunk size when NSUB > 1)
+    if constexpr (NSUB <= 4) {                   // few groups: all their taps formed up front
+        f32x2 g[NSUB][8];
 #pragma unroll
-    for (int u = 0; u < NSUB; ++u)
+        for (int u = 0; u < NSUB; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                g[u][j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al[u], al[u]},
+                                                    f32x2{hv[j].x, hv[j].y});
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int delta = 8 * I + j - 32;
+#pragma unroll
+            for (int o = 0; o < 32; ++o) {
+                const int a = o - delta;
+                if (a >= 0 && a < 32) fma2(acc[o], xr[a], g[a / G][j]);
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) {             // many groups: one at a time, eight formed taps live
+        f32x2 g[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            g[u][j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al[u], al[u]},
-                                                f32x2{hv[j].x, hv[j].y});
+            g[j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al[u], al[u]}, f32x2{hv[j].x, hv[j].y});
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int delta = 8 * I + j - 32;
+        for (int j = 0; j < 8; ++j) {
+            const int delta = 8 * I + j - 32;
 #pragma unroll
-        for (int o = 0; o < 32; ++o) {
-            const int a = o - delta;
-            if (a >= 0 && a < 32) fma2(acc[o], xr[a], g[a / (32 / NSUB)][j]);
+            for (int o = 0; o < 32; ++o) {
+                const int a = o - delta;
+                if (a >= u * G && a < (u + 1) * G && a >= 0 && a < 32) fma2(acc[o], xr[a], g[j]);
+            }
         }
     }
 }
@@ -984,7 +1004,8 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     RenderPlan p = {};
     p.kind = KIND_GENERIC;
     const bool s_pow2 = (S & (S - 1)) == 0;
-    const bool hd_small_s = s_pow2 && (S == 16 || S == 8) && K % 32 == 0;     // rows of 32 hold 2 / 4 subchunks
+    const bool hd_small_s = s_pow2 && S >= 4 && S < 32 && K % 32 == 0;        // rows of 32 hold 2 / 4 / 8 subchunks
+                                                                              // (16 / 32 per row build for minutes: not offered)
     const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
     if (!(aligned && n_src > 0 && T_in > 0)) return p;
     if (!(S % 32 == 0 || hd_small_s)) {
@@ -1139,14 +1160,19 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     const int nsub = S >= 32 ? 1 : 32 / S;
     BAS_REQUIRE(!fused || nsub == 1, BAS_E_SHAPE, "bas_render_mix_fused_f32: subchunks shorter than 32 are not fused");
     typedef void (*hd_fn)(RenderArgs, int);
-    hd_fn hdk = fused ? bas_render_hd_kernel<true, 1>
-                      : (nsub == 1 ? bas_render_hd_kernel<false, 1>
-                                   : (nsub == 2 ? bas_render_hd_kernel<false, 2> : bas_render_hd_kernel<false, 4>));
+    auto pick = [&](bool honly) -> hd_fn {
+        switch (nsub) {
+        case 1: return honly ? bas_render_hd_kernel<false, 1, true> : bas_render_hd_kernel<false, 1>;
+        case 2: return honly ? bas_render_hd_kernel<false, 2, true> : bas_render_hd_kernel<false, 2>;
+        case 4: return honly ? bas_render_hd_kernel<false, 4, true> : bas_render_hd_kernel<false, 4>;
+        default: return honly ? bas_render_hd_kernel<false, 8, true> : bas_render_hd_kernel<false, 8>;
+        }
+    };
+    hd_fn hdk = fused ? bas_render_hd_kernel<true, 1> : pick(false);
     if (p.kind == KIND_HD && p.dual)
         hdk = p.honly ? bas_render_hd_kernel<false, 1, true, true> : bas_render_hd_kernel<false, 1, false, true>;
     else if (p.kind == KIND_HD && p.honly)
-        hdk = nsub == 1 ? bas_render_hd_kernel<false, 1, true>
-                        : (nsub == 2 ? bas_render_hd_kernel<false, 2, true> : bas_render_hd_kernel<false, 4, true>);
+        hdk = pick(true);
     const void *fn = p.kind == KIND_HD ? reinterpret_cast<const void *>(hdk)
                                         : reinterpret_cast<const void *>(bas_render_rows32_kernel);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);

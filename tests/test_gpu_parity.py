@@ -224,6 +224,9 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
                                                    ("", 2, 20000, 96, 48, 128),          # dual, 90 slots
                                                    ("", 2, 20000, 250, 50, 128),         # dual, T_in % 4 != 0 (padded row stride)
                                                    ("", 3, 20001, 333, 37, 100),         # odd everything
+                                                   ("", 2, 20000, 512, 4, 128),          # 8 subchunks per row
+                                                   ("", 2, 20000, 256, 4, 100),          # 8 per row, h-only image
+                                                   ("", 2, 3000, 512, 1, 128),           # a new IR every sample: generic
                                                    ("", 2, 9000, 36, 36, 128)])          # image does not fit: generic
 def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_src, n, k, s, l):
     """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL."""
