@@ -516,14 +516,14 @@ __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4
     hd_row_step_x<NSUB, HONLY>(acc, xr, hdrow, al, live_mask);
 }
 
-// DUAL: any chunk size (multiple of 4) and any subchunk size >= 32.  A row of 32 inputs then meets at most one
-// subchunk (or chunk) boundary, at an input p that differs from lane to lane: the row step runs once on the
-// inputs before p with their (slot, alpha) and once more on the rest with the next subchunk's - twice the FMAs,
-// still an order of magnitude ahead of the generic kernel.
+// DUAL: any chunk size >= 32 and any subchunk size.  A row of 32 inputs then meets subchunk (or chunk) boundaries
+// at inputs that differ from lane to lane: the row step runs once per part of the row, on that part's inputs
+// (the others zeroed) with its (slot, alpha) - two parts for subchunks >= 32 (twice the FMAs), up to
+// ceil(32 / S) + 1 below that; still far ahead of the generic kernel.
 template <bool FUSED, int NSUB, bool HONLY = false, bool DUAL = false>
 __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs A, int nslots) {
     static_assert(!(FUSED && HONLY), "the h-only image is staged from H");
-    static_assert(!DUAL || (NSUB == 1 && !FUSED), "dual rows: subchunks of at least 32 samples, unfused");
+    static_assert(!DUAL || (NSUB == 1 && !FUSED), "multi-part rows: one alpha per part, unfused");
     extern __shared__ f32x4 lds4[];
     f32x4 *xs4 = lds4;                                       // [8][HD_XR] float4
     float *hd = reinterpret_cast<float *>(lds4) + HD_X_FLOATS;   // [nslots][HD_SLOT]
@@ -795,23 +795,28 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                 int r = m_in - q * A.S;
                 if (r < 0) { q -= 1; r += A.S; }
                 if (r >= A.S) { q += 1; r -= A.S; }
-                const int p = A.S - r;                       // inputs [0, p) of the row lie in that subchunk (p > 32: all)
-                const int j_next = (q + 1) * A.S;            // start of the next subchunk inside the chunk
-                const bool wraps = j_next >= A.K;            // ... or the first subchunk of the next chunk
                 const int tap_off = (32 * rp - 32) * (HONLY ? 2 : 4);
                 const int slot_f = HONLY ? HO_SLOT : HD_SLOT;
-                float xa[32];
-                hd_load_xrow(xa, xrow);
+                // the row's inputs [a0, a1) lie in subchunk q of chunk slot `slot`; walk the parts until every
+                // lane of the wave is through its row (S >= 32: at most two parts; S = 10: up to five)
+                int a0 = 0, slot = sl;
+                int a1 = A.S - r;                            // inputs left in the first subchunk
+                while (__any(a0 < 32)) {
+                    float xa[32];
+                    hd_load_xrow(xa, xrow);                  // read again per part rather than hold 32 more registers
 #pragma unroll
-                for (int a = 0; a < 32; ++a) xa[a] = a < p ? xa[a] : 0.f;
-                float al[1] = {(float)(q * A.S) * invK};
-                hd_row_step_x<1, HONLY>(acc, xa, hd + sl * slot_f + tap_off, al, mask_of(rp));
-                if (__any(p < 32)) {                         // some row of this wave meets a boundary
-                    hd_load_xrow(xa, xrow);                  // read again rather than hold 32 more registers
-#pragma unroll
-                    for (int a = 0; a < 32; ++a) xa[a] = a < p ? 0.f : xa[a];
-                    float al2[1] = {wraps ? 0.f : (float)j_next * invK};
-                    hd_row_step_x<1, HONLY>(acc, xa, hd + (sl + (wraps ? 1 : 0)) * slot_f + tap_off, al2, mask_of(rp));
+                    for (int a = 0; a < 32; ++a) xa[a] = (a >= a0 && a < a1) ? xa[a] : 0.f;
+                    float al[1] = {(float)(q * A.S) * invK};
+                    hd_row_step_x<1, HONLY>(acc, xa, hd + slot * slot_f + tap_off, al, mask_of(rp));
+                    if (a1 < 32) {                           // next subchunk; past the chunk's last one: next chunk, alpha 0
+                        q += 1;
+                        if (q * A.S >= A.K) {
+                            q = 0;
+                            slot += 1;
+                        }
+                    }
+                    a0 = a1;                                 // (a finished lane keeps a0 >= 32: its parts are empty)
+                    a1 = a1 + A.S;
                 }
                 step_done();
             }
@@ -1009,14 +1014,14 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
     if (!(aligned && n_src > 0 && T_in > 0)) return p;
     if (!(S % 32 == 0 || hd_small_s)) {
-        // Any other subchunk size >= 32 (any chunk size; the caller keeps rows 16-byte aligned through x_stride): the
-        // hd kernel's dual row step.  One slot more than the rows reach: the part of a row behind a chunk
+        // Any other subchunk size >= 5 (any chunk size >= 32; the caller keeps rows 16-byte aligned through x_stride):
+        // the hd kernel's multi-part row step.  One slot more than the rows reach: the part of a row behind a chunk
         // boundary reads the next chunk's slot.
         const int dual_slots = (K - 1 + 32 * (HD_ROWS - 1) + 31) / K + 2;
         const bool full = dual_slots <= HD_MAXSLOTS;
         const size_t lds = full ? (size_t)(HD_X_FLOATS + (dual_slots + 1) * HD_SLOT) * sizeof(float)
                                 : (size_t)(HD_X_FLOATS + (dual_slots + 1) * HO_SLOT) * sizeof(float);
-        if (S < 32 || lds > 160 * 1024 || (force && strcmp(force, "hd"))) return p;
+        if (S < 5 || K < 32 || lds > 160 * 1024 || (force && strcmp(force, "hd"))) return p;
         p.kind = KIND_HD;
         p.dual = 1;
         p.honly = !full;
