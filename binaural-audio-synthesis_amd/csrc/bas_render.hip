@@ -757,9 +757,19 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             }
             return mk;
         };
+        const bool s_is_pow2 = (A.S & (A.S - 1)) == 0;       // uniform
+        const float invS1 = 1.0f / (float)A.S;
         auto step_setup = [&](int rp, float (&al)[NSUB], const float *&hdrow) {
             if (NSUB == 1) {
-                al[0] = (float)(m_in - (m_in & (A.S - 1))) * invK;           // S is a power of two here
+                if (s_is_pow2) {
+                    al[0] = (float)(m_in - (m_in & (A.S - 1))) * invK;
+                } else {                                     // any multiple of 32: m_in / S by float estimate, corrected
+                    int q = (int)((float)m_in * invS1);
+                    int r = m_in - q * A.S;
+                    if (r < 0) q -= 1;
+                    if (r >= A.S) q += 1;
+                    al[0] = (float)(q * A.S) * invK;
+                }
             } else {
 #pragma unroll
                 for (int u = 0; u < NSUB; ++u) al[u] = (float)(m_in + u * (32 / NSUB)) * invK;   // S = 32 / NSUB
@@ -1046,7 +1056,7 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     // chunks put more slots under a tile and use the h-only image (half the bytes per slot, d taken in the row
     // step: two workgroups per CU down to K ~ 192, one below).  On the 256-source scene: 0.89 ms at K = 256,
     // S = 32 (rows32: 1.24 ms), 0.93 ms at K = 256, S = 16 and 1.2 ms at K = 128, S = 16 (generic: 32 ms).
-    const bool hd_fits = s_pow2 && (hd_slots <= HD_MAXSLOTS ||
+    const bool hd_fits = (s_pow2 || S % 32 == 0) && (hd_slots <= HD_MAXSLOTS ||
                                     (size_t)(HD_X_FLOATS + (hd_slots + 1) * HO_SLOT) * sizeof(float) <= 160 * 1024);
     int kind = hd_fits ? KIND_HD : KIND_ROWS32;
     if (force && !strcmp(force, "rows32")) kind = KIND_ROWS32;

@@ -131,10 +131,10 @@ size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S, int L);
 /* Name of the FIR kernel bas_render_mix_f32 launches for these sizes with aligned
  * operands ("bas_render_hd_kernel", "bas_render_rows32_kernel" or
  * "bas_render_generic_kernel"); for profiling tools.  The hd kernel (fast path) serves
- * chunk sizes from about 72 samples up with any subchunk size >= 4: powers of two with
- * K % 32 == 0 at full speed, other sizes through a multi-part row step (2 to 5 times
- * the arithmetic); rows32 serves subchunk sizes that are multiples of 32 but not powers
- * of two; everything else runs the plain generic kernel. */
+ * chunk sizes from about 72 samples up with any subchunk size >= 4: multiples of 32 (and
+ * 16 / 8 / 4 with K % 32 == 0) at full speed, other sizes through a multi-part row step
+ * (2 to 5 times the arithmetic); rows32 serves smaller chunks with subchunks that are
+ * multiples of 32; everything else runs the plain generic kernel. */
 const char *bas_render_kernel_name(int n_src, long T_in, int K, int S, int L);
 
 int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,

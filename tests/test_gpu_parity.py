@@ -232,6 +232,9 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
                                                    ("", 2, 20000, 100, 20, 128),         # multi-part + h-only image
                                                    ("", 2, 20000, 120, 24, 300),         # ... + three tap segments
                                                    ("", 2, 20000, 40, 5, 128),           # 8 parts per row; 214 slots: generic
+                                                   ("", 3, 20000, 480, 96, 128),         # hd, subchunk a multiple of 32, not a power of two
+                                                   ("", 2, 20000, 320, 160, 100),        # ... with the h-only image
+                                                   ("rows32", 2, 20000, 480, 96, 128),
                                                    ("", 2, 9000, 36, 36, 128)])          # image does not fit: generic
 def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_src, n, k, s, l):
     """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL."""
@@ -278,7 +281,8 @@ def test_kernel_selection():
     assert lib.bas_render_kernel_name(256, 441344, 128, 16, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 64, 32, 128) == b"bas_render_rows32_kernel"    # 131 chunk slots: no fit
     assert lib.bas_render_kernel_name(256, 441344, 64, 16, 128) == b"bas_render_generic_kernel"
-    assert lib.bas_render_kernel_name(256, 441600, 480, 96, 128) == b"bas_render_rows32_kernel"   # S not a power of two
+    assert lib.bas_render_kernel_name(256, 441600, 480, 96, 128) == b"bas_render_hd_kernel"       # any multiple of 32
+    assert lib.bas_render_fused_supported(256, 441600, 480, 96, 128) == 1
     assert lib.bas_render_kernel_name(256, 441000, 1000, 100, 128) == b"bas_render_hd_kernel"     # dual row step
     assert lib.bas_render_kernel_name(256, 441000, 1000, 50, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441000, 1000, 25, 128) == b"bas_render_hd_kernel"       # three parts per row
@@ -290,7 +294,7 @@ def test_kernel_selection():
     assert lib.bas_render_kernel_name(256, 441344, 512, 16, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 512, 8, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 464, 16, 128) == b"bas_render_hd_kernel"       # K % 32 != 0: multi-part rows
-    assert lib.bas_render_kernel_name(256, 441344, 480, 96, 128) == b"bas_render_rows32_kernel"   # S not a power of two
+    assert lib.bas_render_kernel_name(256, 441344, 32, 32, 128) == b"bas_render_rows32_kernel"    # tiny chunks, rows of 32
 
 
 def test_long_ir_segments(tables):
@@ -727,10 +731,10 @@ def test_random_shape_sweep(tables):
         if bas._hip.lib().bas_render_fused_supported(n_src, in_length, k, s_, l):
             fz = bas.render_sources(sigs, k, s_, elev, azim, d, normalize="none", fused=True).cpu().numpy()
             assert rel_err(fz, want) <= REL, (case, "fused", l, k, s_)
-    assert {"bas_render_hd_kernel", "bas_render_rows32_kernel"} <= seen, seen
+    assert "bas_render_hd_kernel" in seen, seen
 
 
-@pytest.mark.parametrize("k,s", [(512, 32), (480, 96), (464, 16), (128, 16)])     # hd, rows32, generic, hd h-only
+@pytest.mark.parametrize("k,s", [(512, 32), (480, 96), (464, 16), (128, 16), (64, 32), (24, 3)])   # hd variants, rows32, generic
 def test_accumulate_into_existing_mix(dev_tables, k, s):
     """bas_render_mix_f32 with accumulate != 0 adds into y (include/bas.h) and reports the peak of the sum:
     rendering sources in two calls equals rendering them in one."""
