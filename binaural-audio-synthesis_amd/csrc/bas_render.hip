@@ -1024,14 +1024,14 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
     if (!(aligned && n_src > 0 && T_in > 0)) return p;
     if (!(S % 32 == 0 || hd_small_s)) {
-        // Any other subchunk size >= 5 (any chunk size >= 32; the caller keeps rows 16-byte aligned through x_stride):
+        // Any other subchunk size >= 2 (any chunk size >= 32; the caller keeps rows 16-byte aligned through x_stride):
         // the hd kernel's multi-part row step.  One slot more than the rows reach: the part of a row behind a chunk
         // boundary reads the next chunk's slot.
         const int dual_slots = (K - 1 + 32 * (HD_ROWS - 1) + 31) / K + 2;
         const bool full = dual_slots <= HD_MAXSLOTS;
         const size_t lds = full ? (size_t)(HD_X_FLOATS + (dual_slots + 1) * HD_SLOT) * sizeof(float)
                                 : (size_t)(HD_X_FLOATS + (dual_slots + 1) * HO_SLOT) * sizeof(float);
-        if (S < 5 || K < 32 || lds > 160 * 1024 || (force && strcmp(force, "hd"))) return p;
+        if (S < 2 || K < 32 || lds > 160 * 1024 || (force && strcmp(force, "hd"))) return p;
         p.kind = KIND_HD;
         p.dual = 1;
         p.honly = !full;

@@ -235,6 +235,8 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
                                                    ("", 3, 20000, 480, 96, 128),         # hd, subchunk a multiple of 32, not a power of two
                                                    ("", 2, 20000, 320, 160, 100),        # ... with the h-only image
                                                    ("rows32", 2, 20000, 480, 96, 128),
+                                                   ("", 2, 20000, 300, 3, 128),          # 12 parts per row
+                                                   ("", 2, 20000, 502, 2, 100),          # 17 parts per row, T_in % 4 != 0
                                                    ("", 2, 9000, 36, 36, 128)])          # image does not fit: generic
 def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_src, n, k, s, l):
     """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL."""
@@ -286,7 +288,8 @@ def test_kernel_selection():
     assert lib.bas_render_kernel_name(256, 441000, 1000, 100, 128) == b"bas_render_hd_kernel"     # dual row step
     assert lib.bas_render_kernel_name(256, 441000, 1000, 50, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441000, 1000, 25, 128) == b"bas_render_hd_kernel"       # three parts per row
-    assert lib.bas_render_kernel_name(256, 441000, 1000, 2, 128) == b"bas_render_generic_kernel"   # S < 5
+    assert lib.bas_render_kernel_name(256, 441000, 1000, 2, 128) == b"bas_render_hd_kernel"        # 17 parts per row
+    assert lib.bas_render_kernel_name(256, 441000, 1000, 1, 128) == b"bas_render_generic_kernel"   # a new IR every sample
     assert lib.bas_render_kernel_name(256, 441000, 30, 10, 128) == b"bas_render_generic_kernel"    # K < 32
     assert lib.bas_render_kernel_name(256, 441090, 490, 49, 128) == b"bas_render_hd_kernel"        # any chunk size
     assert lib.bas_render_fused_supported(256, 441000, 1000, 100, 128) == 0
