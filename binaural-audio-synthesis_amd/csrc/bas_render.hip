@@ -404,14 +404,16 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
 // (H_c, H_{c+1} - H_c) interleaved per tap as (h0_L, h0_R, d_L, d_R); the lane forms
 // g = h0 + al d (al = its row's crossfade weight) with one packed FMA per tap, 6 % on top of the FIR.
 // Nothing row-specific is staged, so a pass costs two barriers and a few dozen LDS stores; with ~71 KB
-// of LDS two 4-wave workgroups share a CU.  Needs S a power of two (>= 32; or 16 / 8 with K a multiple
-// of 32: a row then holds 2 / 4 subchunks, each with its own formed taps) and at most 20 chunk
-// slots per tile (K >= 448).
+// of LDS two 4-wave workgroups share a CU.  Variants (template parameters of the kernel below):
+//   NSUB   S = 16 / 8 / 4 with K a multiple of 32: a row holds 2 / 4 / 8 subchunks, each with its own formed taps
+//   HONLY  more than HD_MAXSLOTS chunk slots under a tile (K < 448): the slots hold (h_L, h_R) only
+//   DUAL   any other subchunk / chunk size: the row step runs once per part of a row (multi-part rows)
+//   FUSED  the chunk IRs are evaluated from the table while staging (bas_render_mix_fused_f32)
 #define HD_NW 4                               // waves per workgroup: one per SIMD, so the CU stays balanced
 #define HD_THREADS (64 * HD_NW)
 #define HD_TILE (2048 * HD_NW)                // outputs per tile
 #define HD_HALO (RT_SEG / 32)                 // input rows above a tile (4)
-#define HD_ROWS (HD_TILE / 32 + HD_HALO)      // rows in the x window (132)
+#define HD_ROWS (HD_TILE / 32 + HD_HALO)      // rows in the x window (260)
 #define HD_XR (HD_ROWS + 1)                   // odd: conflict-free column-major image
 #define HD_NX ((HD_ROWS * 8 + HD_THREADS - 1) / HD_THREADS)     // float4 of x per thread (9)
 #define HD_SLOT (RT_SEG * 4 + 4)              // floats per chunk slot (+16 B: slots on distinct banks)
