@@ -4,27 +4,37 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (config 4 of BASELINE.json, per GPU): 256 concurrent moving sources x 10 s of
-44.1 kHz mono, chunk K=512, subchunk S=32, IR L=128 taps (samples_to_keep=128, U=8),
-synthetic table + seeded noise + per-source spiral/circle trajectories,
-mixed to one stereo pair.  One "step" = one full pass of the hot path over that batch
-with inputs resident in HBM: bas_interp2d_f32 (all chunk IRs) -> bas_render_mix_f32 (time-varying FIR + overlap-add + mix +
-fused peak) -> [N>1: one RCCL gather of the
-partial mixes to rank 0 + fixed-order sum] -> peak rule.
+`python bench.py --gpus N` from a plain shell (no WORLD_SIZE) starts the N ranks itself through
+torch.distributed.run - before anything touches the GPU - and relays rank 0's JSON line.
 
-Scaling is WEAK: every GPU renders its own 256 sources (the scene has 256*N sources)
-and the per-GPU partial mixes meet in ONE gather.  `value` = stereo output samples per
-second of 256-source scene equivalents = N * T_out * steps / wall; at N=1 this is
-exactly BASELINE.json's "stereo samples/sec for 256 concurrent moving sources".
+Workload = BASELINE config 4: ONE scene of 256 concurrent moving sources x 10 s of 44.1 kHz mono, chunk K=512,
+subchunk S=32, IR L=128 taps (samples_to_keep=128, U=8), synthetic table + seeded noise + per-source
+spiral / askew-circle trajectories, mixed to one stereo pair.  One "step" = one full pass of
+the reference's make_signal_move_2d path over that scene with inputs resident in HBM when the timed region
+starts - the audio AND the trajectories (elev, azim per chunk boundary, float64):
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
-(dominant kernel = the FIR kernel, timed live with HIP events) and `cpu_baseline`
-(the oracle's numpy port of the reference loop, timed on this box's host cores).
+    bas_traj_params_f64        a3: angles -> (4 directions, 3 weights) per chunk boundary (sphere.py:78-121,
+                               apply_hrtf.py:199-215, :261-266)
+    bas_interp2d_plan_f32      delays, shift splits, folded blend weights (apply_hrtf.py:219-279)
+    bas_render_mix_fused_f32   chunk IRs from the table + time-varying FIR + overlap-add + mix + fused peak
+    [N>1: one RCCL gather of the partial mixes to rank 0 + fixed-order sum]
+    bas_scale_by_peak_f32      the peak rule (apply_hrtf.py:462-464)
+
+Scaling: with N > 1 the ONE scene is sharded by source over the GPUs (config 4 read literally: strong scaling,
+`value` = that scene's stereo samples per second).  The same invocation then also times the weak reading (every
+GPU renders its own 256 sources) and reports it under "extra": {"weak": ...}.  `--scaling weak` makes weak the
+headline instead.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the FIR
+kernel, timed live with HIP events on the launch stream) and `cpu_baseline` (the oracle's numpy port of the
+reference loop, timed on this box's host cores).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,9 +53,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--sources", type=int, default=256, help="sources per GPU (weak) / in the whole scene (strong)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default): every GPU renders --sources sources; strong: BASELINE config 4 read "
-                         "literally, ONE --sources-source scene sharded over the GPUs")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default): BASELINE config 4 read literally, ONE --sources-source scene sharded "
+                         "over the GPUs; weak: every GPU renders --sources sources")
+    ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the second (weak) measurement")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--subchunk", type=int, default=32)
@@ -121,6 +132,9 @@ def cpu_baseline(args, n, t_out):
     scene_seconds = max(busy) * args.sources / n_rendered
     one_core_scene_seconds = sorted(busy)[len(busy) // 2] * args.sources / per
     return {"value": t_out / scene_seconds, "unit": "stereo samples/s", "cores": cores, "kind": "port",
+            "note": "the numpy port (per-subchunk np.convolve, vectorised shifts) runs ~5x faster per core than the "
+                    "reference's own Python loop it stands in for (BASELINE.md 2: 8.8-11 x real time per core): "
+                    "the baseline is conservative in the CPU's favour",
             "sample": f"{n_rendered} of {args.sources} sources x {n} samples ({per} per core, {cores} processes, "
                       f"slowest worker {max(busy):.1f} s of rendering, {wall:.1f} s wall incl. process start), "
                       f"extrapolated linearly to {args.sources} sources",
@@ -229,134 +243,147 @@ def stream_mode(args):
         dist.destroy_process_group()
 
 
-def main():
-    args = parse()
-    if args.mode == "stream":
-        return stream_mode(args)
-    import numpy as np
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks through torch.distributed.run and relay
+    rank 0's line.  Nothing here touches the GPU (device_count() does not initialise it), the ranks are child
+    processes.  On a box with fewer devices than ranks this becomes the one-device rehearsal (all ranks on
+    cuda:0, gather staged through the host under gloo; the line says so) - at most 4 ranks."""
+    import torch
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        if args.gpus > 4:
+            print(f"bench.py: {args.gpus} ranks asked, {n_dev} device(s) visible: refusing to stack more than 4 "
+                  f"ranks on one device", file=sys.stderr)
+            return 2
+        env["BAS_BENCH_ONE_DEVICE"] = "1"
+        env["BAS_BENCH_BACKEND"] = "gloo"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+class Scene:
+    """One rank's share of a scene, resident in HBM, and the step that renders it."""
+
+    def __init__(self, args, bas, dev, world, rank, scaling, tbl, host_u):
+        import numpy as np
+        import torch
+        from binaural_audio_synthesis_amd import _hip
+        self.args, self.bas, self.dev, self.world, self.rank, self.scaling = args, bas, dev, world, rank, scaling
+        self.tbl = tbl
+        n = int(round(args.seconds * FS))
+        k, s, l = args.chunk, args.subchunk, args.taps
+        if scaling == "strong":                                  # one scene, sources split over the ranks
+            mine = bas.distributed.shard_sources(args.sources, world, rank)
+            n_src, first_src, total_src = len(mine), mine.start, args.sources
+        else:                                                    # every rank its own args.sources sources
+            n_src, first_src, total_src = args.sources, rank * args.sources, args.sources * world
+        self.n, self.n_src, self.total_src = n, n_src, total_src
+        self.in_length = in_length = -(-n // k) * k
+        self.t_out = t_out = in_length + l - 1
+        self.n_q = n_q = in_length // k + 1
+        gen = torch.Generator(device=dev).manual_seed(1000 + rank + (17 if scaling == "weak" else 0))
+        self.x = torch.zeros((n_src, in_length), dtype=torch.float32, device=dev)
+        self.x[:, :n] = (torch.rand((n_src, n), generator=gen, device=dev) * 2 - 1) * (1.0 / total_src)
+        tq = np.arange(0, in_length + 1, k, dtype=np.float64)
+        elev = np.empty((n_src, n_q))
+        azim = np.empty((n_src, n_q))
+        for i in range(n_src):
+            elev[i], azim[i] = source_trajectory(bas.synth, first_src + i, total_src, n)(tq)
+        # the trajectories are INPUTS of the timed step (device float64), not precomputed parameters
+        self.elev = torch.from_numpy(elev).to(dev)
+        self.azim = torch.from_numpy(azim).to(dev)
+        self.idx = torch.empty((n_src * n_q, 4), dtype=torch.int32, device=dev)
+        self.w = torch.empty((n_src * n_q, 3), dtype=torch.float64, device=dev)
+        lib = _hip.lib()
+        self.ws = torch.empty((lib.bas_render_workspace_bytes(n_src, in_length, k, s, l),), dtype=torch.uint8, device=dev)
+        self.ws_i = torch.empty((lib.bas_interp2d_workspace_bytes(n_src * n_q),), dtype=torch.uint8, device=dev)
+        self.y = torch.empty((2, t_out), dtype=torch.float32, device=dev)
+        self.parts = torch.empty((world, 2, t_out), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
+        self.y_final = torch.empty((2, t_out), dtype=torch.float32, device=dev)
+        self.peak = torch.empty((1,), dtype=torch.float32, device=dev)
+        env_fused = os.environ.get("BAS_BENCH_FUSED")            # ablation: "0" forces interp2d + render_mix
+        self.fused = None if env_fused is None else env_fused == "1"
+        self.fused_used = bool(lib.bas_render_fused_supported(n_src, in_length, k, s, l)) and self.fused is not False
+        self.kernel = lib.bas_render_kernel_name(n_src, in_length, k, s, l).decode()
+        self.host_u = host_u
+
+    def render_into(self, y_buf, events):
+        """a3 -> plans -> (chunk IRs +) FIR + mix + peak, all on the current stream."""
+        bas, a = self.bas, self.args
+        bas.sphere.interpolation_params_device(self.elev, self.azim, out=(self.idx, self.w))
+        return bas.apply_hrtf.render_params_device(self.x, a.chunk, a.subchunk, self.tbl, self.idx, self.w,
+                                                   normalize="none", out=y_buf, events=events, ws=self.ws,
+                                                   ws_plans=self.ws_i, fused=self.fused)[1]
+
+
+def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_events):
+    """Warm up, time exactly args.steps steps (barrier + synchronize on both sides, max over ranks) and return
+    (elapsed seconds, scene, FIR kernel milliseconds per launch or None)."""
     import torch
     import torch.distributed as dist
-    import binaural_audio_synthesis_amd as bas
     from binaural_audio_synthesis_amd import _hip
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    # rehearsal knobs (a 1-GPU box): BAS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0,
-    # BAS_BENCH_BACKEND=gloo stages the gather through host memory.  The driver's runs use neither.
-    if os.environ.get("BAS_BENCH_ONE_DEVICE") == "1":
-        local_rank = 0
-    backend = os.environ.get("BAS_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
-    n = int(round(args.seconds * FS))
-    k, s, l, n_src = args.chunk, args.subchunk, args.taps, args.sources
-    if args.scaling == "strong":                             # one scene, sources split over the ranks
-        n_src = len(bas.distributed.shard_sources(args.sources, world, rank))
-    in_length = -(-n // k) * k
-    t_out = in_length + l - 1
-    n_q = in_length // k + 1
-
-    # ---- inputs, resident in HBM before the timed region ---------------------------------
-    host = bas.synth.make_table("consistent", 0).truncated(l)
-    tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left,
-                                 host.irs_right, device=dev)
-    gen = torch.Generator(device=dev).manual_seed(1000 + rank)
-    total_src = n_src * world if args.scaling == "weak" else args.sources
-    first_src = rank * n_src if args.scaling == "weak" else bas.distributed.shard_sources(args.sources, world, rank).start
-    x = torch.zeros((n_src, in_length), dtype=torch.float32, device=dev)
-    x[:, :n] = (torch.rand((n_src, n), generator=gen, device=dev) * 2 - 1) * (1.0 / total_src)
-    tq = np.arange(0, in_length + 1, k, dtype=np.float64)
-    elev = np.empty((n_src, n_q))
-    azim = np.empty((n_src, n_q))
-    for i in range(n_src):
-        elev[i], azim[i] = source_trajectory(bas.synth, first_src + i, total_src, n)(tq)
-    idx_h, w_h = bas.sphere.interpolation_params_batch(elev, azim)
-    idx = torch.from_numpy(idx_h.reshape(-1, 4)).to(dev)
-    w = torch.from_numpy(w_h.reshape(-1, 3)).to(dev)
-    y = torch.empty((2, t_out), dtype=torch.float32, device=dev)
-    ws = torch.empty((_hip.lib().bas_render_workspace_bytes(n_src, in_length, k, s, l),), dtype=torch.uint8,
-                     device=dev)
-    ws_i = torch.empty((_hip.lib().bas_interp2d_workspace_bytes(n_src * n_q),), dtype=torch.uint8, device=dev)
-    parts = torch.empty((world, 2, t_out), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
-    y_final = torch.empty((2, t_out), dtype=torch.float32, device=dev)
-    peak = torch.empty((1,), dtype=torch.float32, device=dev)
-    ev = HipEvents(args.steps)
-
-    fused = os.environ.get("BAS_BENCH_FUSED", "0") == "1"   # chunk IRs inside the FIR kernel (bas_render_mix_fused_f32)
-
-    def render_into(y_buf, i_event):
-        events = None if i_event is None else ev.pairs[i_event]
-        return bas.apply_hrtf.render_params_device(x, k, s, tbl, idx, w, normalize="none", out=y_buf, events=events,
-                                                   ws=ws, ws_plans=ws_i, fused=fused)[1]
+    sc = Scene(args, bas, dev, world, rank, scaling, tbl, host_u)
+    t_out = sc.t_out
+    ev = HipEvents(args.steps) if with_events else None
 
     def mix_on_root(parts_buf):
         stream = _hip.current_stream(dev)
-        _hip.call("bas_mix_partials_f32", _hip.ptr(parts_buf), world, 2 * t_out, 2 * t_out, _hip.ptr(y_final),
-                  _hip.ptr(peak), stream)
-        _hip.call("bas_scale_by_peak_f32", _hip.ptr(y_final), 2 * t_out, _hip.ptr(peak), stream)
+        _hip.call("bas_mix_partials_f32", _hip.ptr(parts_buf), world, 2 * t_out, 2 * t_out, _hip.ptr(sc.y_final),
+                  _hip.ptr(sc.peak), stream)
+        _hip.call("bas_scale_by_peak_f32", _hip.ptr(sc.y_final), 2 * t_out, _hip.ptr(sc.peak), stream)
 
-    def step_sync(i_event=None):
-        pk = render_into(y, i_event)
-        if world > 1 and backend != "nccl":              # rehearsal only: gather through host memory
-            y_host = y.cpu()
-            if rank == 0:
-                host_parts = [torch.empty_like(y_host) for _ in range(world)]
-                dist.gather(y_host, gather_list=host_parts, dst=0)
-                parts.copy_(torch.stack(host_parts))
-            else:
-                dist.gather(y_host, gather_list=None, dst=0)
-        elif world > 1:
-            dist.gather(y, gather_list=list(parts.unbind(0)) if rank == 0 else None, dst=0)
-        if world > 1:
-            if rank == 0:
-                mix_on_root(parts)
-        else:
-            _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(pk), _hip.current_stream(dev))
+    def step_single(i_event=None):
+        pk = sc.render_into(sc.y, None if (ev is None or i_event is None) else ev.pairs[i_event])
+        _hip.call("bas_scale_by_peak_f32", _hip.ptr(sc.y), 2 * t_out, _hip.ptr(pk), _hip.current_stream(dev))
 
     # N > 1: the gather of step i travels (RCCL stream, xGMI) while step i+1 renders; y and the root's receive
     # buffer are double-buffered, the root sums step i right after it has launched step i+1's gather.  Every
     # collective is issued by all ranks in step order; drain() inside the timed region completes the last one.
     # BAS_BENCH_SYNC_GATHER=1 restores gather-then-continue.
     overlap = world > 1 and os.environ.get("BAS_BENCH_SYNC_GATHER", "0") != "1"
-    ys = [y, torch.empty_like(y)] if overlap else [y]
-    parts2 = [parts, torch.empty_like(parts)] if (overlap and rank == 0) else [parts]
+    ys = [sc.y, torch.empty_like(sc.y)] if overlap else [sc.y]
+    parts2 = [sc.parts, torch.empty_like(sc.parts)] if (overlap and rank == 0) else [sc.parts]
     inflight = [None, None]
     counter = [0]
 
-    def launch_gather(b):
+    def launch_gather(b, async_op):
         if backend == "nccl":
             work = dist.gather(ys[b], gather_list=list(parts2[b].unbind(0)) if rank == 0 else None, dst=0,
-                               async_op=True)
-            return (work, None, None)
+                               async_op=async_op)
+            return (work, None)
         y_host = ys[b].cpu()                              # rehearsal only: gloo moves host memory
         host_parts = [torch.empty_like(y_host) for _ in range(world)] if rank == 0 else None
-        return (dist.gather(y_host, gather_list=host_parts, dst=0, async_op=True), host_parts, y_host)
+        return (dist.gather(y_host, gather_list=host_parts, dst=0, async_op=async_op), host_parts)
 
     def finish_gather(b):
         if inflight[b] is None:
             return
-        work, host_parts, _ = inflight[b]
-        work.wait()                                       # nccl: the current stream waits, the host does not
+        work, host_parts = inflight[b]
+        if work is not None:
+            work.wait()                                   # nccl: the current stream waits, the host does not
         if rank == 0:
             if host_parts is not None:
                 parts2[b].copy_(torch.stack(host_parts))
             mix_on_root(parts2[b])
         inflight[b] = None
 
+    def step_sync(i_event=None):
+        sc.render_into(ys[0], None if (ev is None or i_event is None) else ev.pairs[i_event])
+        inflight[0] = launch_gather(0, False)
+        finish_gather(0)
+
     def step_overlapped(i_event=None):
         b = counter[0] & 1
         counter[0] += 1
         finish_gather(b)                                  # the collective that read ys[b] two steps ago is done
-        render_into(ys[b], i_event)
-        inflight[b] = launch_gather(b)
+        sc.render_into(ys[b], None if (ev is None or i_event is None) else ev.pairs[i_event])
+        inflight[b] = launch_gather(b, True)
         if rank == 0:
             finish_gather(b ^ 1)                          # previous step: its gather ran beside this render
 
@@ -366,7 +393,7 @@ def main():
             finish_gather(b)                              # older one first
             finish_gather(b ^ 1)
 
-    step = step_overlapped if overlap else step_sync
+    step = step_single if world == 1 else (step_overlapped if overlap else step_sync)
 
     def fence():
         drain()
@@ -384,60 +411,127 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend != "nccl" else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     if overlap and os.environ.get("BAS_BENCH_CHECK") == "1":   # rehearsal: the pipelined mix equals the synchronous one
-        pipelined = y_final.clone() if rank == 0 else None
+        pipelined = sc.y_final.clone() if rank == 0 else None
         step_sync()
         torch.cuda.synchronize(dev)
         if rank == 0:
-            assert torch.equal(pipelined, y_final), "overlapped gather changed the mix"
+            assert torch.equal(pipelined, sc.y_final), "overlapped gather changed the mix"
             print("check: pipelined mix == synchronous mix", file=sys.stderr, flush=True)
+    fir_ms = None
+    if ev is not None:
+        per = [ev.elapsed_ms(i) for i in range(args.steps)]
+        fir_ms = sum(per) / len(per)
+    return elapsed, sc, fir_ms, overlap
 
-    fir_ms = [ev.elapsed_ms(i) for i in range(args.steps)]
-    fir_avg_s = sum(fir_ms) / len(fir_ms) / 1e3
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.mode == "stream":
+        return stream_mode(args)
+    import torch
+    import torch.distributed as dist
+    import binaural_audio_synthesis_amd as bas
+    from binaural_audio_synthesis_amd import _hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal knobs (a 1-GPU box; self_launch sets them when devices are missing): BAS_BENCH_ONE_DEVICE=1 puts
+    # every rank on cuda:0, BAS_BENCH_BACKEND=gloo stages the gather through host memory.
+    rehearsal = os.environ.get("BAS_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local_rank = 0
+    backend = os.environ.get("BAS_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    k, s, l = args.chunk, args.subchunk, args.taps
+    host = bas.synth.make_table("consistent", 0).truncated(l)
+    tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left,
+                                 host.irs_right, device=dev)
+    scaling = args.scaling                                   # (one GPU: the whole scene either way)
+    elapsed, sc, fir_ms, overlap = run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host.upsampling, True)
+    extra = {}
+    if world > 1 and not args.no_extra:
+        other = "weak" if scaling == "strong" else "strong"
+        del sc.x, sc.parts                                   # free the first scene's big buffers
+        e2, sc2, _, _ = run_scene(args, bas, dev, world, rank, backend, other, tbl, host.upsampling, False)
+        scenes2 = world if other == "weak" else 1
+        extra[other] = {"value": scenes2 * sc2.t_out * args.steps / e2, "unit": "stereo samples/s",
+                        "ms_per_step": e2 / args.steps * 1e3, "sources_per_gpu": sc2.n_src,
+                        "scene_sources": sc2.total_src,
+                        "x_realtime": (sc2.n / FS) * scenes2 / (e2 / args.steps),
+                        "meaning": "every GPU renders its own --sources sources; value counts 256-source scene "
+                                   "equivalents" if other == "weak" else "ONE --sources-source scene sharded over the GPUs"}
 
     if rank == 0:
+        n, n_src, in_length, t_out, n_q = sc.n, sc.n_src, sc.in_length, sc.t_out, sc.n_q
         ms_per_step = elapsed / args.steps * 1e3
         # weak: 256-source-scene equivalents per second; strong: the one scene's stereo samples per second
-        scenes = world if args.scaling == "weak" else 1
+        scenes = world if scaling == "weak" else 1
         value = scenes * t_out * args.steps / elapsed
         # algorithmic bytes of one FIR launch: inputs once, stereo mix once,
         # table once, 28 B of parameters per chunk IR
         m_cols = l * host.upsampling
         algo_bytes = 4 * n_src * in_length + 8 * t_out + 4 * (2 * 187 * m_cols + 2 * 187 * 187) + 28 * n_src * n_q
         algo_flops = 4 * l * n_src * in_length            # 2 ears x L FMA per source-sample
-        traffic = None
+        fir_s = fir_ms / 1e3
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "fir_hbm_traffic.json")
         if os.path.exists(tpath):
             with open(tpath) as f:
                 rec = json.load(f)
-            if rec.get("workload") == f"{n_src}x{n}@K{k}S{s}L{l}":
+            if rec.get("workload") == f"{n_src}x{n}@K{k}S{s}L{l}" and rec.get("fused", False) == sc.fused_used:
                 traffic = rec.get("bytes_per_launch")
+                traffic_source = "profiles/fir_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this " \
+                                 "workload, gfx950 correction applied; replayed, not measured in this run)"
         out = {
-            "metric": "stereo samples/sec, 256 concurrent moving sources per GPU @44.1kHz (x real-time in x_realtime)",
+            "metric": "stereo samples/sec, 256 concurrent moving sources @44.1kHz mixed to one stereo pair "
+                      "(x real-time in x_realtime)",
             "value": value, "unit": "stereo samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 4 per GPU: {n_src} moving sources x {args.seconds:g} s @ {FS} Hz mono "
+            "config": {"workload": f"BASELINE config 4: {sc.total_src} moving sources x {args.seconds:g} s @ {FS} Hz mono "
                                    f"-> 1 stereo mix; chunk {k}, subchunk {s}, {l}-tap HRIRs (U=8, 187 directions), "
-                                   f"spiral/askew-circle trajectories; scene = {total_src} sources on {world} GPU(s)",
-                       "sources_per_gpu": n_src, "samples_per_source": n, "chunk": k, "subchunk": s, "taps": l,
-                       "out_samples": t_out, "parallelism": f"sources sharded over {world} GPU(s), 1 gather per step" +
-                                                      (", travelling beside the next step's render" if overlap else "")},
+                                   f"spiral/askew-circle trajectories given as (elev, azim) per chunk boundary on the "
+                                   f"device; step = angles->parameters (a3) + read plans + "
+                                   + ("fused chunk-IR evaluation/FIR/overlap-add/mix" if sc.fused_used else
+                                      "chunk IRs (interp2d) + FIR/overlap-add/mix")
+                                   + f" + peak rule; {n_src} sources on this GPU, {world} GPU(s)",
+                       "sources_per_gpu": n_src, "scene_sources": sc.total_src, "samples_per_source": n, "chunk": k,
+                       "subchunk": s, "taps": l, "out_samples": t_out, "fused": sc.fused_used,
+                       "parallelism": f"sources sharded over {world} GPU(s), 1 gather per step" +
+                                      (", travelling beside the next step's render" if overlap else "")},
             "x_realtime": (n / FS) * scenes / (elapsed / args.steps),
-            "source_samples_per_s": total_src * in_length * args.steps / elapsed,
-            "roofline": {"bound": "hbm", "achieved": algo_bytes / fir_avg_s / 1e9, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": algo_bytes / fir_avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": _hip.lib().bas_render_kernel_name(n_src, in_length, k, s, l).decode(), "kernel_ms": fir_avg_s * 1e3,
-                         "algorithmic_bytes": algo_bytes},
-            "valu": {"achieved": algo_flops / fir_avg_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": algo_flops / fir_avg_s / 1e12 / FP32_VALU_PEAK_TF,
+            "source_samples_per_s": sc.total_src * in_length * args.steps / elapsed,
+            "roofline": {"bound": "hbm", "achieved": algo_bytes / fir_s / 1e9, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": algo_bytes / fir_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_source,
+                         "kernel": sc.kernel + (" (fused: chunk IRs evaluated while staging)" if sc.fused_used else ""),
+                         "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes},
+            "valu": {"achieved": algo_flops / fir_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": algo_flops / fir_s / 1e12 / FP32_VALU_PEAK_TF,
                      "note": "the FIR is 128 flop/B: fp32-VALU bound, HBM fraction tops out near 15 %; peak is nominal "
-                             "(2.4 GHz) - a bare v_pk_fma_f32 stream on random operands sustains 97 TFLOP/s here "
-                             "(power-limited clock, tools/ubench_fir_pattern.hip, DESIGN.md 4)"},
+                             "(2.4 GHz) - a bare v_pk_fma_f32 stream on random operands sustains ~97 TFLOP/s "
+                             "(power-limited clock; profiles/r02_ubench_*.txt, DESIGN.md 4)"},
         }
+        if extra:
+            out["extra"] = extra
+        if rehearsal:
+            out["rehearsal"] = f"{world} ranks on ONE device, gather staged through host memory ({backend}): " \
+                               "a functional check of the multi-rank path, not a scaling measurement"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, n, t_out)
         print(json.dumps(out), flush=True)

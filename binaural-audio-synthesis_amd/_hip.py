@@ -45,6 +45,7 @@ SIGNATURES = {
 }
 
 _lib = None
+DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libbas_hip_diag.so")   # -DBAS_DIAG build: reads BAS_FORCE_KERNEL (tests only)
 
 
 class BasError(RuntimeError):
@@ -53,22 +54,44 @@ class BasError(RuntimeError):
         self.code = code
 
 
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C {os.path.dirname(path)}`.  There is no CPU fallback.")
+    handle = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(handle, name)              # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if handle.bas_version() != 1:
+        raise RuntimeError(f"{os.path.basename(path)} ABI version {handle.bas_version()} != 1")
+    return handle
+
+
 def lib():
     """The loaded library (loads on first use; raises if it has not been built)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                f"or `make -C {os.path.dirname(LIB_PATH)}`.  There is no CPU fallback.")
-        handle = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(handle, name)          # AttributeError if the symbol is not exported
-            fn.restype, fn.argtypes = res, args
-        if handle.bas_version() != 1:
-            raise RuntimeError(f"libbas_hip.so ABI version {handle.bas_version()} != 1")
-        _lib = handle
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+class use_library:
+    """Context manager for tests and ablations: route every call of this process through another build of the
+    same ABI (e.g. DIAG_LIB_PATH, the only build that honours BAS_FORCE_KERNEL) and restore the shipped one."""
+
+    def __init__(self, path):
+        self.handle = _load(path)
+
+    def __enter__(self):
+        global _lib
+        self.saved, _lib = _lib, self.handle
+        return self.handle
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self.saved
+        return False
 
 
 def call(name, *args):

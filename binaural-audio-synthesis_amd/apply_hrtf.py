@@ -67,21 +67,38 @@ def load_irs_and_delaydiffs(filename='irs_and_delaydiffs_compensated_6.mat', sam
                               rec['irs_left'][:, :keep], rec['irs_right'][:, :keep], device=device)
 
 
+def _table_key(tbl):
+    """What a cached device copy of a foreign table struct was made from: the identity and shape of its five
+    fields.  Re-binding a field (e.g. re-truncating irs_left) changes the key; in-place edits of the same array
+    cannot be seen and need `del tbl._bas_device_tables`."""
+    return (int(tbl.upsampling),) + tuple((id(a), tuple(np.shape(a))) for a in
+                                          (tbl.diffs_left, tbl.diffs_right, tbl.irs_left, tbl.irs_right))
+
+
 def as_device_table(tbl, device=None):
     """Accept this module's table, or any object with the reference's five attributes
-    holding numpy arrays (e.g. the reference's own class-as-struct); the device copy
-    is cached on the object."""
+    holding numpy arrays (e.g. the reference's own class-as-struct).  The device copy of a
+    foreign struct is cached on the object per (device, field identities): another GPU or a
+    re-bound field gets its own copy."""
     if isinstance(tbl, irs_and_delaydiffs):
         return tbl
-    cached = getattr(tbl, "_bas_device_table", None)
-    if cached is None:
-        cached = irs_and_delaydiffs(tbl.upsampling, tbl.diffs_left, tbl.diffs_right,
-                                    tbl.irs_left, tbl.irs_right, device=device)
+    device = _hip.require_gpu(device)
+    key = _table_key(tbl)
+    cache = getattr(tbl, "_bas_device_tables", None)            # {device: (key, device table)}
+    hit = cache.get(str(device)) if cache is not None else None
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    made = irs_and_delaydiffs(tbl.upsampling, tbl.diffs_left, tbl.diffs_right,
+                              tbl.irs_left, tbl.irs_right, device=device)
+    if cache is None:
+        cache = {}
         try:
-            tbl._bas_device_table = cached
+            tbl._bas_device_tables = cache
         except (AttributeError, TypeError):
             pass
-    return cached
+    # the arrays are kept alive with the entry so that their id()s cannot be reused by later allocations
+    cache[str(device)] = (key, made, (tbl.diffs_left, tbl.diffs_right, tbl.irs_left, tbl.irs_right))
+    return made
 
 
 # --------------------------------------------------------------------------
@@ -246,11 +263,11 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     dev = x.device
     n_src, t_in = x.shape
     lib = _hip.lib()
-    if fused is None:
-        fused = os.environ.get("BAS_FUSED", "0") == "1"
+    if fused is None:                                         # default: fused wherever the kernel serves the shape
+        fused = os.environ.get("BAS_FUSED", "1") != "0"
     if fused:
         fused = bool(lib.bas_render_fused_supported(n_src, t_in, chunksize, subchunksize, tbl.L)) and \
-            x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
+            tbl.upsampling >= 4 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
     n_q = idx.shape[0]
     if not fused:
         H = interpolate_2d_params(tbl, idx, w, validate=False, ws=ws_plans)

@@ -122,6 +122,7 @@ __device__ __forceinline__ float tab_read(const float *__restrict__ packed, int 
                                            int m, int L, int U, int ush, int M) {
     int cc = c - j;
     if (cc < 0) cc += M;
+    if (cc < 0) cc = bas_pmod(cc, M);                        // tables shorter than the five-sample reach (M < 5)
     int ph, o;
     if (POW2) {
         ph = cc & (U - 1);
@@ -293,6 +294,52 @@ __global__ __launch_bounds__(256) void bas_interp2d_eval_kernel(const float *__r
     }
 }
 
+// Any upsampling factor: the planned evaluation above steps through up to five consecutive upsampled
+// positions with "previous plane, or plane + U one sample earlier" (bas_plan.h), which needs U >= 4.  Tables
+// with U = 1, 2, 3 (the reference accepts any factor, apply_hrtf.py:38) take this plain form instead: one
+// thread per output tap, every table sample addressed through tab_read's general position arithmetic.
+__global__ __launch_bounds__(256) void bas_interp2d_generic_kernel(const float *__restrict__ packed,
+                                                                     const double *__restrict__ diffs,
+                                                                     const int32_t *__restrict__ idx,
+                                                                     const double *__restrict__ w, long n,
+                                                                     int ndir, int L, int U,
+                                                                     float *__restrict__ H) {
+    const int M = L * U;
+    const long total = n * 2 * L;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256L) {
+        const long qe = i / L;
+        const int m = (int)(i - qe * L);
+        const long q = qe >> 1;
+        const int e = (int)(qe & 1);
+        const int pt = clamp_dir(idx[4 * q + 0], ndir), qt = clamp_dir(idx[4 * q + 1], ndir);
+        const int pb = clamp_dir(idx[4 * q + 2], ndir), qb = clamp_dir(idx[4 * q + 3], ndir);
+        const double at = w[3 * q + 0], ab = w[3 * q + 1], a = w[3 * q + 2];
+        const double *d = diffs + (long)e * ndir * ndir;
+        const double dt = (at * ((double)U * d[(long)pt * ndir + qt])) / (double)U;   // apply_hrtf.py:106
+        const double db = (ab * ((double)U * d[(long)pb * ndir + qb])) / (double)U;
+        const double dv = (double)U * (-dt + d[(long)pt * ndir + pb] + db);           // :246-252
+        float f3, f4;
+        const int b3 = bas_split_shift_mod(-dv, M, f3);                               // :254-255
+        const int b4 = bas_split_shift_mod((1.0 - a) * dv, M, f4);                    // :272-277
+        RingPlan top, bot;
+        double s2;
+        const int c_top = bas_submod(0, b4, M);
+        ring_plan(top, d, e, ndir, pt, qt, at, L, U, c_top, s2);
+        ring_plan(bot, d, e, ndir, pb, qb, ab, L, U, bas_submod(c_top, b3, M), s2);
+        float rb[3], rt[2];
+        ring_eval<false, 3>(packed, bot, m, L, U, 0, M, rb);
+        ring_eval<false, 2>(packed, top, m, L, U, 0, M, rt);
+        const float af = (float)a;
+        float c[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float sb = (1.0f - f3) * rb[j] + f3 * rb[j + 1];                    // S(R_b, -Dv)
+            c[j] = (1.0f - af) * sb + af * rt[j];                                      // :268-269
+        }
+        H[i] = (1.0f - f4) * c[0] + f4 * c[1];                                         // :276-277
+    }
+}
+
 extern "C" size_t bas_interp2d_workspace_bytes(int n) {
     return n > 0 ? (size_t)n * 2 * sizeof(EarPlanW) + 16 : 16;
 }
@@ -303,6 +350,9 @@ extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, co
     BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
                 "bas_interp2d_plan_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
     BAS_REQUIRE((long)2 * ndir * BAS_PLANE(L) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_plan_f32: table too large");
+    BAS_REQUIRE(U >= BAS_PLAN_MIN_U, BAS_E_SHAPE,
+                "bas_interp2d_plan_f32: read plans need an upsampling factor >= %d (U=%d): use bas_interp2d_f32",
+                BAS_PLAN_MIN_U, U);
     if (n == 0) return 0;
     BAS_REQUIRE(plans && plans_bytes >= bas_interp2d_workspace_bytes(n) &&
                     reinterpret_cast<uintptr_t>(plans) % 16 == 0,
@@ -328,6 +378,13 @@ extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const 
     EarPlanW *plans = reinterpret_cast<EarPlanW *>(ws);
     hipStream_t st = bas_stream(stream);
     const long rows = 2L * n;
+    if (U < BAS_PLAN_MIN_U) {                                // small upsampling factors: plain evaluation
+        long blocks = ((long)n * 2 * L + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(bas_interp2d_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, diffs, idx,
+                           w, (long)n, ndir, L, U, H);
+        return bas_check_launch("bas_interp2d_f32(generic)");
+    }
     hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
                        w, n, ndir, L, U, plans);
     int rc = bas_check_launch("bas_interp2d_f32(plan)");

@@ -7,6 +7,10 @@
 // first three samples], so a lane can read up to 4 consecutive taps and "one sample earlier" unconditionally.
 #define BAS_PLANE(L) ((L) + 4)
 
+// A read set steps through up to five consecutive upsampled positions as "previous plane, or plane + U one
+// sample earlier" (set_dot*): valid while 4 <= U.  Smaller factors use bas_interp2d_f32's plain kernel.
+#define BAS_PLAN_MIN_U 4
+
 struct SetPlan {
     int base;          // float index of plane ph0's sample 0 in `packed` (guard is at base - 1)
     int ph0;           // phase of read j = 0; reads j <= ph0 stay in plane ph0 - j at offset o,

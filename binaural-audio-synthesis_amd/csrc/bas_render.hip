@@ -27,6 +27,8 @@
 #include "bas_plan.h"
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 
 #define RT_THREADS 256
 #define RT_TILE 2048            // outputs per tile: 64 lanes x 32
@@ -48,12 +50,22 @@ struct RenderArgs {
     int units_per_wg;
     int parts_per_wg;
     float *slab;           // [n_wg][parts_per_wg][2][RT_TILE]
-    int dbg;               // ablation flags (BAS_DEBUG_FLAGS, diagnostics only)
+#ifdef BAS_DIAG
+    int dbg;               // ablation flags (BAS_DEBUG_FLAGS; diagnostic build only, make diag)
+#endif
     // fused path (chunk IRs evaluated from read plans inside the FIR kernel, H unused)
     const float *packed;   // table in phase-plane layout
     const int *plans;      // [n_src][n_chunks+1][2 ears][32 words]
     int U;
 };
+
+// Ablation switches exist only in the diagnostic build (make diag / make stamps -> libbas_hip_diag.so,
+// libbas_hip_stamps.so); the shipped library has no environment hooks and no way to skip work.
+#ifdef BAS_DIAG
+#define BAS_DBG(A, bit) (((A).dbg & (bit)) != 0)
+#else
+#define BAS_DBG(A, bit) false
+#endif
 
 #ifdef BAS_STAMPS
 // Diagnostic build only (make stamps): per-wave cycle totals of the pass loop phases.
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
             v = inside ? v : f32x4{0.f, 0.f, 0.f, 0.f};
             if (i4 < nrows * 8) xs4[(i4 & 7) * RT_XR + (i4 >> 3)] = v;
         }
-        if (2 * lane < P.Lseg && !(A.dbg & 1)) {
+        if (2 * lane < P.Lseg && !BAS_DBG(A, 1)) {
             const int k0 = P.seg0 + 2 * lane;
             const f32x2 live = f32x2{k0 < A.L ? 1.0f : 0.0f, k0 + 1 < A.L ? 1.0f : 0.0f};   // taps >= L are zero
             f32x4 *gdst = reinterpret_cast<f32x4 *>(gs) + lane;
@@ -369,7 +381,7 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
             cur_tile = P.tile;
         }
         STAMP(t1);
-        if (!(A.dbg & 2)) fir_pass(P);
+        if (!BAS_DBG(A, 2)) fir_pass(P);
         STAMP(t2);
         __syncthreads();                                     // every wave has finished reading LDS
         STAMP(t3);
@@ -554,7 +566,11 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
     float *slab_wg = A.slab + (long)blockIdx.x * A.parts_per_wg * 2 * HD_TILE;
     const float invK = 1.0f / (float)A.K;
     const unsigned prio_flip = blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u;
-    const int prio_slice = (A.dbg >> 8) & 31 ? (A.dbg >> 8) & 31 : ((A.dbg & 16) ? 0 : 12);   // default 2^12 ticks = 41 us
+#ifdef BAS_DIAG
+    const int prio_slice = (A.dbg >> 8) & 31 ? (A.dbg >> 8) & 31 : ((A.dbg & 16) ? 0 : 12);
+#else
+    constexpr int prio_slice = 12;                           // priority slices of 2^12 ticks = 41 us
+#endif
 
     auto flush = [&](long tile) {
         float *dst = slab_wg + (tile - first_tile) * 2 * HD_TILE + 2048 * wv + 32 * lane;
@@ -992,14 +1008,54 @@ static int grid_for(long items, int cap) {
     return (int)(g < cap ? g : cap);
 }
 
+// Per-device facts and one-time kernel attributes, cached: bas_render_mix_f32 is called once per block by the
+// streaming renderer, so nothing on its path may query the runtime or the environment per call.
+#define BAS_MAX_DEVICES 64
+static std::atomic<int> g_cus[BAS_MAX_DEVICES];
+
+static int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        dev = 0;
+    }
+    return dev;
+}
+
 static int device_cus() {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
+    const int dev = current_device();
+    const bool cached = dev >= 0 && dev < BAS_MAX_DEVICES;
+    int cus = cached ? g_cus[dev].load(std::memory_order_relaxed) : 0;
+    if (cus > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) {
         (void)hipGetLastError();
         cus = 256;                                           // MI355X
     }
+    if (cached) g_cus[dev].store(cus, std::memory_order_relaxed);
     return cus;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, raised once per (kernel, device) to the whole LDS
+static hipError_t allow_full_lds(const void *fn) {
+    static std::mutex mu;
+    static struct { const void *fn; unsigned long long devs; } seen[64];
+    static int n_seen = 0;
+    const int dev = current_device();
+    const unsigned long long bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lock(mu);
+    int slot = -1;
+    for (int i = 0; i < n_seen; ++i)
+        if (seen[i].fn == fn) slot = i;
+    if (slot >= 0 && (seen[slot].devs & bit)) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    if (slot < 0 && n_seen < 64) {
+        slot = n_seen++;
+        seen[slot].fn = fn;
+        seen[slot].devs = 0;
+    }
+    if (slot >= 0) seen[slot].devs |= bit;
+    return hipSuccess;
 }
 
 enum { KIND_GENERIC = 0, KIND_ROWS32 = 1, KIND_HD = 2 };
@@ -1023,7 +1079,11 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     const bool s_pow2 = (S & (S - 1)) == 0;
     const bool hd_small_s = s_pow2 && S >= 4 && S < 32 && K % 32 == 0;        // rows of 32 hold 2 / 4 / 8 subchunks
                                                                               // (16 / 32 per row build for minutes: not offered)
-    const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostics / tests only
+#ifdef BAS_DIAG
+    const char *force = getenv("BAS_FORCE_KERNEL");          // diagnostic build only: tests force the fallback kernels
+#else
+    const char *force = nullptr;
+#endif
     if (!(aligned && n_src > 0 && T_in > 0)) return p;
     if (!(S % 32 == 0 || hd_small_s)) {
         // Any other subchunk size >= 2 (any chunk size >= 32; the caller keeps rows 16-byte aligned through x_stride):
@@ -1172,7 +1232,9 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     A.K = K; A.S = S; A.L = L; A.Lp = (L + 7) & ~7; A.n_chunks = n_chunks;
     A.units_total = p.units_total; A.units_per_wg = p.units_per_wg; A.parts_per_wg = p.parts_per_wg;
     A.slab = reinterpret_cast<float *>(ws);
+#ifdef BAS_DIAG
     { const char *d = getenv("BAS_DEBUG_FLAGS"); A.dbg = d ? atoi(d) : 0; }
+#endif
     A.packed = packed; A.plans = reinterpret_cast<const int *>(plans); A.U = U;
     const int nsub = S >= 32 ? 1 : 32 / S;
     BAS_REQUIRE(!fused || nsub == 1, BAS_E_SHAPE, "bas_render_mix_fused_f32: subchunks shorter than 32 are not fused");
@@ -1192,7 +1254,7 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
         hdk = pick(true);
     const void *fn = p.kind == KIND_HD ? reinterpret_cast<const void *>(hdk)
                                         : reinterpret_cast<const void *>(bas_render_rows32_kernel);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes);
+    hipError_t e = allow_full_lds(fn);
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
     if (p.kind == KIND_HD)
@@ -1234,7 +1296,8 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
                                         int accumulate, float *peak, void *ws, size_t ws_bytes,
                                         bas_stream_t stream, void *ev_begin, void *ev_end) {
     BAS_REQUIRE(packed && plans, BAS_E_NULL, "bas_render_mix_fused_f32: packed or plans is null");
-    BAS_REQUIRE(U > 0, BAS_E_SHAPE, "bas_render_mix_fused_f32: U must be positive");
+    BAS_REQUIRE(U >= BAS_PLAN_MIN_U, BAS_E_SHAPE, "bas_render_mix_fused_f32: needs an upsampling factor >= %d (U=%d)",
+                BAS_PLAN_MIN_U, U);
     BAS_REQUIRE(reinterpret_cast<uintptr_t>(plans) % 16 == 0, BAS_E_ALIGN,
                 "bas_render_mix_fused_f32: plans must be 16-byte aligned");
     return render_mix_impl(x, x_stride, nullptr, n_src, T_in, K, S, L, y, accumulate, peak, ws, ws_bytes, stream,

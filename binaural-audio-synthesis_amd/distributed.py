@@ -135,12 +135,18 @@ def render_time_sharded(signals, chunksize, subchunksize, elev, azim, tbl, ir_le
         pad = max(sizes)
         buf = torch.zeros((pad, 2), dtype=mine.dtype, device=mine.device)
         buf[:mine.shape[0]] = mine
+        # gloo cannot gather device tensors: stage through host memory (rehearsal on boxes without RCCL peers;
+        # the production backend "nccl" gathers device to device over xGMI)
+        via_host = buf.is_cuda and dist.get_backend(group) == "gloo"
+        send = buf.cpu() if via_host else buf
         if rank == dst:
-            parts = [torch.empty_like(buf) for _ in range(world)]
-            dist.gather(buf, gather_list=parts, dst=dst, group=group)
+            parts = [torch.empty_like(send) for _ in range(world)]
+            dist.gather(send, gather_list=parts, dst=dst, group=group)
             full = torch.cat([parts[r][:sizes[r]] for r in range(world)], dim=0)
+            if via_host:
+                full = full.to(mine.device)
         else:
-            dist.gather(buf, gather_list=None, dst=dst, group=group)
+            dist.gather(send, gather_list=None, dst=dst, group=group)
             return None
     if normalize == "mix":
         peak = full.abs().max().reshape(1)

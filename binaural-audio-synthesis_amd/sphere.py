@@ -219,13 +219,27 @@ def interpolation_params_batch(elev, azim):
 
 
 _DEVICE_NODES = {}
+_RING_ARGS = None
 
 
-def interpolation_params_device(elev, azim):
+def _ring_args():
+    """The ten rings as host ctypes arrays (built once): what bas_traj_params_f64 takes by value."""
+    global _RING_ARGS
+    if _RING_ARGS is None:
+        import ctypes
+        ring_elev = (ctypes.c_double * 10)(*[float(v) for v in _AVAILABLE_ELEVS])
+        ring_start = (ctypes.c_int32 * 10)(*RING_START)
+        ring_count = (ctypes.c_int32 * 10)(*RING_COUNTS)
+        _RING_ARGS = (ring_elev, ring_start, ring_count,
+                      ctypes.addressof(ring_elev), ctypes.addressof(ring_start), ctypes.addressof(ring_count))
+    return _RING_ARGS[3:]
+
+
+def interpolation_params_device(elev, azim, out=None):
     """interpolation_params_batch on the GPU (bas_traj_params_f64): elev/azim are float64 device
-    tensors of equal shape; returns device tensors idx int32 [..., 4], w float64 [..., 3].
+    tensors of equal shape; returns device tensors idx int32 [..., 4], w float64 [..., 3] (written into
+    `out` = (idx, w) when given: contiguous tensors of those shapes, no allocation per call).
     Non-finite angles are not diagnosed here (the host form raises ValueError)."""
-    import ctypes
     import torch
     from . import _hip
     assert elev.is_cuda and elev.dtype == torch.float64 and azim.shape == elev.shape and azim.dtype == torch.float64
@@ -236,12 +250,14 @@ def interpolation_params_device(elev, azim):
     e = elev.contiguous().reshape(-1)
     z = azim.contiguous().reshape(-1)
     n = e.numel()
-    idx = torch.empty((n, 4), dtype=torch.int32, device=dev)
-    w = torch.empty((n, 3), dtype=torch.float64, device=dev)
-    ring_elev = (ctypes.c_double * 10)(*[float(v) for v in _AVAILABLE_ELEVS])
-    ring_start = (ctypes.c_int32 * 10)(*RING_START)
-    ring_count = (ctypes.c_int32 * 10)(*RING_COUNTS)
-    _hip.call("bas_traj_params_f64", _hip.ptr(e), _hip.ptr(z), n, ctypes.addressof(ring_elev),
-              ctypes.addressof(ring_start), ctypes.addressof(ring_count), _hip.ptr(nodes), _hip.ptr(idx), _hip.ptr(w),
-              _hip.current_stream(dev))
+    if out is None:
+        idx = torch.empty((n, 4), dtype=torch.int32, device=dev)
+        w = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    else:
+        idx, w = out
+        assert idx.is_contiguous() and w.is_contiguous() and idx.numel() == 4 * n and w.numel() == 3 * n
+        assert idx.dtype == torch.int32 and w.dtype == torch.float64 and idx.device == dev and w.device == dev
+    ring_elev, ring_start, ring_count = _ring_args()
+    _hip.call("bas_traj_params_f64", _hip.ptr(e), _hip.ptr(z), n, ring_elev, ring_start, ring_count,
+              _hip.ptr(nodes), _hip.ptr(idx), _hip.ptr(w), _hip.current_stream(dev))
     return idx.reshape(tuple(elev.shape) + (4,)), w.reshape(tuple(elev.shape) + (3,))

@@ -239,12 +239,10 @@ def test_render_sources_vs_oracle(dev_tables, n_src, n, k, s, l):
                                                    ("", 2, 20000, 502, 2, 100),          # 17 parts per row, T_in % 4 != 0
                                                    ("", 2, 9000, 36, 36, 128)])          # image does not fit: generic
 def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_src, n, k, s, l):
-    """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL."""
-    if force:
-        monkeypatch.setenv("BAS_FORCE_KERNEL", force)
-    name = bas._hip.lib().bas_render_kernel_name(n_src, -(-n // k) * k, k, s, l).decode()
-    if force:
-        assert force in name
+    """The three FIR kernels (hd, rows32, generic) are interchangeable: same result within REL.  Forcing a
+    kernel is a feature of the diagnostic build only (libbas_hip_diag.so, -DBAS_DIAG): those cases run through
+    it; the others through the shipped library, unfused and - where the fused kernel serves the shape - fused."""
+    import contextlib
     if ("consistent", l) not in dev_tables:
         h = tables["consistent"].truncated(l)
         d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
@@ -252,8 +250,36 @@ def test_every_fir_kernel_vs_oracle(dev_tables, tables, monkeypatch, force, n_sr
         h, d = dev_tables[("consistent", l)]
     sigs, elev, azim, irs = _mix_case(h, n_src, n, k, s, seed=700)
     want = orc.render_mix(sigs, k, s, irs)
-    got = bas.render_sources(sigs, k, s, elev, azim, d).cpu().numpy()
+    in_length = -(-n // k) * k
+    if force:
+        monkeypatch.setenv("BAS_FORCE_KERNEL", force)
+    with (bas._hip.use_library(bas._hip.DIAG_LIB_PATH) if force else contextlib.nullcontext()):
+        name = bas._hip.lib().bas_render_kernel_name(n_src, in_length, k, s, l).decode()
+        if force:
+            assert force in name
+        got = bas.render_sources(sigs, k, s, elev, azim, d, fused=False).cpu().numpy()
     assert rel_err(got, want) <= REL, (name, rel_err(got, want))
+    if not force and bas._hip.lib().bas_render_fused_supported(n_src, in_length, k, s, l):
+        fz = bas.render_sources(sigs, k, s, elev, azim, d).cpu().numpy()          # the default: fused
+        assert rel_err(fz, want) <= REL, (name, "fused", rel_err(fz, want))
+
+
+def test_shipped_library_has_no_diagnostic_hooks(dev_tables, monkeypatch):
+    """BAS_FORCE_KERNEL / BAS_DEBUG_FLAGS are compiled out of libbas_hip.so: with both set the shipped library
+    picks the same kernel and renders the same audio (the diagnostic build would run the generic kernel and
+    skip the FIR)."""
+    import torch
+    h, d = dev_tables[("consistent", 128)]
+    sigs, elev, azim, irs = _mix_case(h, 3, 9000, 512, 32, seed=31)
+    before = bas.render_sources(sigs, 512, 32, elev, azim, d)
+    monkeypatch.setenv("BAS_FORCE_KERNEL", "generic")
+    monkeypatch.setenv("BAS_DEBUG_FLAGS", "3")
+    assert bas._hip.lib().bas_render_kernel_name(3, 9216, 512, 32, 128) == b"bas_render_hd_kernel"
+    after = bas.render_sources(sigs, 512, 32, elev, azim, d)
+    assert torch.equal(before, after)
+    assert rel_err(after.cpu().numpy(), orc.render_mix(sigs, 512, 32, irs)) <= REL
+    with bas._hip.use_library(bas._hip.DIAG_LIB_PATH):
+        assert bas._hip.lib().bas_render_kernel_name(3, 9216, 512, 32, 128) == b"bas_render_generic_kernel"
 
 
 @pytest.mark.parametrize("n_src,n,k,s,l", [(5, 20000, 512, 32, 128), (2, 9000, 1024, 64, 100), (2, 9000, 512, 32, 300)])
@@ -529,6 +555,32 @@ def test_device_params_kernel_is_bit_identical_to_host():
     assert np.array_equal(w_d.cpu().numpy(), w_h)
 
 
+def test_device_params_kernel_against_reference_goldens():
+    """bas_traj_params_f64 checked DIRECTLY against values the unmodified reference produced
+    (tests/golden/azim_params.npz: sphere.azim_to_interpolation_params with np.float64 azimuths, 576 points incl.
+    exact nodes, 0, 2 pi, 2 pi - eps, negative and > 2 pi azimuths, the 60 / 75 degree rings and the pole).
+    The fixture's elevations are database rings, so the bracket degenerates (top ring = bottom ring, a = 0):
+    idx = (before, after, before, after), w = (a_ring, a_ring, 0)."""
+    import torch
+    gp = golden("azim_params.npz")
+    idx_d, w_d = bas.sphere.interpolation_params_device(torch.from_numpy(gp["elev"].astype(np.float64)).cuda(),
+                                                        torch.from_numpy(gp["azim"].astype(np.float64)).cuda())
+    idx_d, w_d = idx_d.cpu().numpy(), w_d.cpu().numpy()
+    assert np.array_equal(idx_d[:, 0], gp["before_f64"]) and np.array_equal(idx_d[:, 1], gp["after_f64"])
+    assert np.array_equal(idx_d[:, 2], gp["before_f64"]) and np.array_equal(idx_d[:, 3], gp["after_f64"])
+    assert np.array_equal(w_d[:, 0], gp["a_f64"]) and np.array_equal(w_d[:, 1], gp["a_f64"])
+    assert not w_d[:, 2].any()
+    # and the device table arithmetic on those parameters equals the reference's interpolate_2d goldens
+    g = golden("interp2d.npz")
+    pts = g["points"]
+    idx_p, w_p = bas.sphere.interpolation_params_device(torch.from_numpy(pts[:, 0].copy()).cuda(),
+                                                        torch.from_numpy(pts[:, 1].copy()).cuda())
+    h = bas.synth.make_table("consistent", 0).truncated(128)
+    d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    got = bas.interpolate_2d_params(d, idx_p, w_p).cpu().numpy()
+    assert rel_err(got, g["consistent_128"]) <= REL
+
+
 def test_integration_md_stub_runs(tables):
     """The ctypes stub printed in INTEGRATION.md is real code: run it (with this repo's sphere module
     standing in for the reference's, same interface) on a golden case."""
@@ -639,15 +691,39 @@ def test_bench_contract_line():
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None
-    assert d["dtype"] == "f32" and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["scaling"] == "strong" and d["higher_is_better"] is True
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert "angles->parameters" in d["config"]["workload"] and d["config"]["fused"] is True
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
-    assert "traffic" in rf and rf["kernel"].startswith("bas_render_")
+    assert "traffic" in rf and "traffic_source" in rf and rf["kernel"].startswith("bas_render_")
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0 and "sample" in cb and cb["unit"] == d["unit"]
     assert d["value"] > cb["value"]
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain shell (no launcher, no WORLD_SIZE): bench.py starts the ranks
+    itself before touching the GPU; on this one-GPU box that is the one-device rehearsal (both ranks on cuda:0,
+    gather staged through the host under gloo).  ONE JSON line: the strong reading of config 4 (one scene,
+    sources sharded) with the weak reading under extra.weak."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BAS_BENCH_CHECK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--sources", "5", "--seconds", "0.5",
+                        "--steps", "3", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3
+    assert d["config"]["scene_sources"] == 5 and d["config"]["sources_per_gpu"] == 3       # rank 0 of a 3 + 2 split
+    assert d["extra"]["weak"]["scene_sources"] == 10 and d["extra"]["weak"]["value"] > 0
+    assert "rehearsal" in d and "cpu_baseline" not in d
+    assert r.stderr.count("check: pipelined mix == synchronous mix") == 2                   # strong and weak runs
 
 
 @pytest.mark.parametrize("scale", ["0.1", "3.0"])

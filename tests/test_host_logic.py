@@ -105,6 +105,35 @@ def test_no_product_module_imports_the_oracle():
                 assert "oracle" not in src.replace("no CPU fallback", ""), f
 
 
+def test_diagnostic_build_is_separate_and_only_it_reads_the_environment():
+    """libbas_hip_diag.so (-DBAS_DIAG) exports the same ABI; the shipped library contains neither hook string."""
+    hip = bas._hip
+    with hip.use_library(hip.DIAG_LIB_PATH) as diag:
+        assert hip.lib() is diag and diag.bas_version() == 1
+    assert hip.lib() is not diag
+    shipped = open(hip.LIB_PATH, "rb").read()
+    assert b"BAS_FORCE_KERNEL" not in shipped and b"BAS_DEBUG_FLAGS" not in shipped
+    assert b"BAS_FORCE_KERNEL" in open(hip.DIAG_LIB_PATH, "rb").read()
+
+
+def test_small_upsampling_factor_is_refused_by_the_planned_entry_points():
+    """the read plans step through phase planes assuming U >= 4; smaller factors must be an error
+    there (bas_interp2d_f32 serves them with its plain kernel), not silent garbage.  Argument checks run before
+    any launch, so this needs no GPU."""
+    import ctypes
+    hip = bas._hip
+    buf = (ctypes.c_char * 4096)()
+    a = ctypes.addressof(buf)
+    a += (-a) % 16
+    for u in (1, 2, 3):
+        with pytest.raises(hip.BasError) as err:
+            hip.call("bas_interp2d_plan_f32", a, a, a, 1, 187, 64, u, a, 4000, None)
+        assert err.value.code == -2 and "upsampling" in str(err.value)
+        with pytest.raises(hip.BasError) as err:
+            hip.call("bas_render_mix_fused_f32", a, 512, a, a, 1, 512, 512, 32, 64, u, a, 0, None, a, 4000, None, None, None)
+        assert err.value.code == -2 and "upsampling" in str(err.value)
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     """No CPU fallback: without the built .so every compute entry point raises."""
     hip = bas._hip
