@@ -33,12 +33,14 @@ def _device_table(h):
 # ---------------------------------------------------------------------------
 # a1: the product's loader
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("keep,case", [(128, "spiral_512_32_128"), (100, "spiral_512_32_100")])
-def test_load_irs_and_delaydiffs_from_mat(tmp_path, tables, keep, case):
+@pytest.mark.parametrize("case", ["spiral_512_32_128", "spiral_512_32_100", "askew_128_16_100"])
+def test_load_irs_and_delaydiffs_from_mat(tmp_path, tables, case):
     """bas.load_irs_and_delaydiffs (apply_hrtf.py:23-46): struct indexing, upsampling as int, truncation to
     samples_to_keep * upsampling columns, then a reference golden rendered through the loaded table."""
+    g = golden(f"render_{case}.npz")
+    meta = json.loads(str(g["meta"]))
+    keep, full = meta["L"], tables[meta["table"]]
     path = str(tmp_path / "irs_and_delaydiffs_synth.mat")
-    full = tables["consistent"]
     bas.synth.save_table_mat(path, full)
     d = bas.load_irs_and_delaydiffs(path, samples_to_keep=keep)
     assert isinstance(d.upsampling, int) and d.upsampling == 8
@@ -48,15 +50,12 @@ def test_load_irs_and_delaydiffs_from_mat(tmp_path, tables, keep, case):
     assert np.array_equal(d.irs_right.cpu().numpy(), want.irs_right.astype(np.float32))
     assert np.array_equal(d.diffs_left.cpu().numpy(), full.diffs_left)
     assert np.array_equal(d.diffs_right.cpu().numpy(), full.diffs_right)
-    g = golden(f"render_{case}.npz")
-    meta = json.loads(str(g["meta"]))
-    assert meta["table"] == "consistent" and meta["L"] == keep
     traj = bas.synth.trajectory(meta["traj"], fs=meta["fs"], **meta["traj_kw"])
     got = bas.make_signal_move_2d(g["x"], meta["K"], meta["S"], traj, d)
     assert got.shape == g["y"].shape and rel_err(got, g["y"]) <= REL
     pts = golden("interp2d.npz")
     one = bas.interpolate_2d(d, np.float64(pts["points"][3, 0]), np.float64(pts["points"][3, 1]))
-    assert rel_err(one, pts[f"consistent_{keep}"][3]) <= REL
+    assert rel_err(one, pts[f"{meta['table']}_{keep}"][3]) <= REL
 
 
 def test_cli_with_table_file(tmp_path, tables):
