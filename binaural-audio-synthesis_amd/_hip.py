@@ -36,8 +36,9 @@ SIGNATURES = {
     "bas_interp2d_plan_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                        _c_void_p, _c_size_t, _c_void_p]),
     "bas_render_fused_supported": (_c_int, [_c_int, _c_long, _c_int, _c_int, _c_int]),
+    "bas_render_fused_workspace_bytes": (_c_size_t, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_mix_fused_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_long, _c_int,
-                                          _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                          _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
                                           _c_size_t, _c_void_p, _c_void_p, _c_void_p]),
     "bas_peak_normalize_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_void_p]),
     "bas_scale_by_peak_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
@@ -45,6 +46,7 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2                                                      # BAS_ABI_VERSION of include/bas.h
 DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libbas_hip_diag.so")   # -DBAS_DIAG build: reads BAS_FORCE_KERNEL (tests only)
 
 
@@ -63,8 +65,8 @@ def _load(path):
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(handle, name)              # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if handle.bas_version() != 1:
-        raise RuntimeError(f"{os.path.basename(path)} ABI version {handle.bas_version()} != 1")
+    if handle.bas_version() != ABI_VERSION:
+        raise RuntimeError(f"{os.path.basename(path)} ABI version {handle.bas_version()} != {ABI_VERSION}")
     return handle
 
 

@@ -279,7 +279,7 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     pb = lib.bas_interp2d_workspace_bytes(n_q)
     if ws_plans is None or ws_plans.numel() < pb:
         ws_plans = torch.empty((pb,), dtype=torch.uint8, device=dev)
-    wb = lib.bas_render_workspace_bytes(n_src, t_in, chunksize, subchunksize, tbl.L)
+    wb = lib.bas_render_fused_workspace_bytes(n_src, t_in, chunksize, subchunksize, tbl.L)
     if ws is None or ws.numel() < wb:
         ws = torch.empty((wb,), dtype=torch.uint8, device=dev)
     stream = _hip.current_stream(dev)
@@ -287,8 +287,8 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
               tbl.upsampling, _hip.ptr(ws_plans), ws_plans.numel(), stream)
     ev = events if events is not None else (None, None)
     _hip.call("bas_render_mix_fused_f32", _hip.ptr(x), x.stride(0), _hip.ptr(tbl.packed), _hip.ptr(ws_plans), n_src,
-              t_in, chunksize, subchunksize, tbl.L, tbl.upsampling, _hip.ptr(y), 0, _hip.ptr(peak), _hip.ptr(ws),
-              ws.numel(), stream, ev[0], ev[1])
+              t_in, chunksize, subchunksize, tbl.L, tbl.upsampling, tbl.ndir, _hip.ptr(y), 0, _hip.ptr(peak),
+              _hip.ptr(ws), ws.numel(), stream, ev[0], ev[1])
     if normalize == "mix":
         _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(peak), stream)
     elif normalize != "none":

@@ -1,0 +1,508 @@
+// a6 + a7 + a8 in one kernel (gfx950): interpolate_2d of every chunk IR a tile needs (apply_hrtf.py:219-279),
+// per-subchunk crossfade (:442-443), direct FIR (:445-446), overlap-add and the mix over sources (:450-453).
+// The [n_src][n_chunks+1][2][L] chunk-IR array of the two-kernel path never exists in HBM.
+//
+// Work split and FIR: as bas_render_hd_kernel (bas_render.hip) - a workgroup of NW waves owns a tile of
+// 2048 NW outputs and walks over (tile, source) units with the mix in registers; lane = one row of 32 outputs;
+// row step = 32 x 32 Toeplitz block of packed FMAs on an x row and 64 (h0, d) taps from LDS (bas_fir.h).
+//
+// What is different here
+//   * chunk IRs come from read plans with precomputed byte offsets (EarPlanS, bas_plan.h).  Wave w evaluates
+//     a contiguous range of chunk IRs: it copies their plans (144 bytes per ear) into its own LDS region, then
+//     per chunk IR lanes 0-31 evaluate four adjacent taps of the left ear, lanes 32-63 of the right ear: every
+//     plan value reaches the lanes of "its" half-wave as a broadcast LDS read, so one IR costs 12 offset ops +
+//     16 address adds + 32 packed FMAs and 16 sixteen-byte table reads per lane (the plan-in-lanes form of
+//     round 1 needed ~195 vector instructions per IR for shuffles and per-read plane selection).
+//   * the wave keeps its chunk IRs in registers, forms d = H_{c+1} - H_c itself, regroups (left, right) with
+//     v_permlane32_swap and stores (h0_L, h0_R, d_L, d_R) with 16-byte LDS writes: no second pass over the
+//     LDS image, one barrier less per pass.
+//   * (tile, source, tap segment) advance by scalar counters and the window's chunk arithmetic is redone only
+//     when the tile changes: no 64-bit divisions per pass; the per-lane chunk slot comes from a float estimate.
+//   * NW = 4, 2 or 1 waves per workgroup (tile 8192 / 4096 / 2048): scenes with few sources (BASELINE configs
+//     2 and 3: ONE source) get four times the workgroups out of the same signal.
+// No MFMA: this is a 1-D FIR (BASELINE.json north_star).
+#include "bas_internal.h"
+#include "bas_plan.h"
+#include "bas_fir.h"
+
+#ifdef BAS_STAMPS
+// Diagnostic build only (make stamps): per-wave totals of the pass phases in 10 ns ticks (s_memrealtime).
+__device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
+#define FZ_STAMP(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define FZ_STAMP_NW(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
+#define FZ_ADD(slot, a, b) st_acc[slot] += (b) - (a)
+#else
+#define FZ_STAMP(var)
+#define FZ_STAMP_NW(var)
+#define FZ_ADD(slot, a, b)
+#endif
+
+#define FZ_MAXSLOTS 20          // chunk slots under one tile (LDS: two 4-wave workgroups per CU at K >= 448)
+
+// (the four arrays are separate __restrict__ kernel parameters, not members: only then can the compiler prove
+// that the slab stores never clobber the plans and fetch them through the scalar cache)
+struct FzArgs {
+    long x_stride;
+    int n_src;
+    long T_in;
+    int K, S, L, Lp;            // Lp = L rounded up to a multiple of 8
+    int n_chunks;
+    int s_pow2;                 // S is a power of two
+    float invK, invS;
+    long units_total;           // n_tiles * n_src
+    int units_per_wg, parts_per_wg;
+    int nslots;                 // chunk slots staged per pass (covers every window of this K and tile)
+    int spw;                    // chunk slots per wave = ceil(nslots / NW)
+    unsigned packed_bytes;
+};
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// Taps m .. m+3 of one chunk IR for this lane's ear: h[m] = sum_k w_k * sample_k(m), 16 table reads in 4 sets
+// (reads 0-4, 5-8, 9-12, 13-15; one wrapped lane offset per set).  pl = this half-wave's plan in LDS (9 x 16
+// bytes: off[16], w[16], o4[4]): all lanes of a half-wave read the same addresses, so those reads are broadcasts.
+// The work is cut in halves of 8 reads so that the caller can keep the loads of the next half in flight while
+// it folds the current one (the compiler, left alone, serialises the loads once registers get tight).
+struct FzHalf {
+    u32x4 v[8];
+};
+
+__device__ __forceinline__ unsigned fz_wrap(unsigned m4, unsigned o4, unsigned L4) {
+    const unsigned idx = m4 + o4;                              // 4 (m + o): m < L, o < L
+    const unsigned wr = idx - L4;
+    return idx < wr ? idx : wr;                                // idx >= 4 L ? idx - 4 L : idx
+}
+
+template <int HSEL>
+__device__ __forceinline__ void fz_issue(__amdgpu_buffer_rsrc_t tab, const f32x4 *__restrict__ pl, unsigned m4,
+                                          unsigned L4, FzHalf &H) {
+    const u32x4 o4 = __builtin_bit_cast(u32x4, pl[8]);
+    const u32x4 pa = __builtin_bit_cast(u32x4, pl[2 * HSEL]), pb = __builtin_bit_cast(u32x4, pl[2 * HSEL + 1]);
+    unsigned a[8];
+    if (HSEL == 0) {                                           // reads 0-4: set 0, reads 5-7: set 1
+        const unsigned s0 = fz_wrap(m4, o4.x, L4), s1 = fz_wrap(m4, o4.y, L4);
+        a[0] = s0 + pa.x; a[1] = s0 + pa.y; a[2] = s0 + pa.z; a[3] = s0 + pa.w;
+        a[4] = s0 + pb.x; a[5] = s1 + pb.y; a[6] = s1 + pb.z; a[7] = s1 + pb.w;
+    } else {                                                   // read 8: set 1, reads 9-12: set 2, reads 13-15: set 3
+        const unsigned s1 = fz_wrap(m4, o4.y, L4), s2 = fz_wrap(m4, o4.z, L4), s3 = fz_wrap(m4, o4.w, L4);
+        a[0] = s1 + pa.x; a[1] = s2 + pa.y; a[2] = s2 + pa.z; a[3] = s2 + pa.w;
+        a[4] = s2 + pb.x; a[5] = s3 + pb.y; a[6] = s3 + pb.z; a[7] = s3 + pb.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) H.v[j] = __builtin_amdgcn_raw_buffer_load_b128(tab, (int)a[j], 0, 0);
+}
+
+template <int HSEL>
+__device__ __forceinline__ f32x4 fz_finish(const f32x4 *__restrict__ pl, const FzHalf &H, f32x4 acc) {
+    const f32x4 wa = pl[4 + 2 * HSEL], wb = pl[5 + 2 * HSEL];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float w = j < 4 ? wa[j] : wb[j - 4];
+        acc = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, H.v[j]), f32x4{w, w, w, w}, acc);
+    }
+    return acc;
+}
+
+// Lanes l < 32 hold four taps of the left ear, lanes l + 32 the same taps of the right ear.  After two half-wave
+// swaps lane l holds taps 2, 3 of both ears and lane l + 32 taps 0, 1 of both ears: (t_a L, t_a R), (t_b L, t_b R).
+__device__ __forceinline__ void fz_pair_ears(const f32x4 &h, f32x2 &ta, f32x2 &tb) {
+    // permlane32_swap(vdst, src): lanes 32-63 of vdst <-> lanes 0-31 of src
+    const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h.z), __float_as_uint(h.x), false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h.w), __float_as_uint(h.y), false, false);
+    // s0[0] = [L t2 | L t0], s0[1] = [R t2 | R t0] (lower lanes | upper lanes); s1 likewise for t3 / t1
+    ta = f32x2{__uint_as_float(s0[0]), __uint_as_float(s0[1])};
+    tb = f32x2{__uint_as_float(s1[0]), __uint_as_float(s1[1])};
+}
+
+template <int XR>
+__device__ __forceinline__ void fz_load_xrow(float (&xr)[32], const f32x4 *__restrict__ xrow) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4 v = xrow[c * XR];
+        xr[4 * c] = v.x; xr[4 * c + 1] = v.y; xr[4 * c + 2] = v.z; xr[4 * c + 3] = v.w;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
+    FzArgs A, const float *__restrict__ x,                   // [n_src] rows of T_in floats, stride A.x_stride
+    float *__restrict__ slab,                                // [n_wg][parts_per_wg][2][tile]
+    const float *__restrict__ packed,                        // table in phase-plane layout
+    const unsigned *__restrict__ plans) {                    // [n_src][n_chunks+1][2 ears][BAS_PLANS_WORDS]
+    constexpr int THREADS = 64 * NW;
+    constexpr int TILE = 2048 * NW;
+    constexpr int ROWS = TILE / 32 + HD_HALO;                // rows of 32 inputs in the x window
+    constexpr int XR = ROWS + 1;                             // odd: conflict-free column-major image
+    constexpr int NX = (ROWS * 8 + THREADS - 1) / THREADS;   // float4 of x per thread (9)
+    constexpr int XFLOATS = 8 * XR * 4;
+    constexpr int MAXEV = NW == 4 ? 6 : 7;                   // chunk IRs one wave evaluates (its slots + 1)
+    static_assert(XR % 2 == 1, "x image rows must be odd");
+    extern __shared__ f32x4 lds4[];
+    f32x4 *xs4 = lds4;                                       // [8][XR] float4
+    float *hd = reinterpret_cast<float *>(lds4) + XFLOATS;   // [nslots][HD_SLOT]: (h0_L, h0_R, d_L, d_R) per tap
+    constexpr int PL4 = 2 * BAS_PLANS_WORDS / 4;             // float4 per chunk IR's pair of plans (18)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const long unit0 = (long)blockIdx.x * A.units_per_wg;
+    long unit1 = unit0 + A.units_per_wg;
+    if (unit1 > A.units_total) unit1 = A.units_total;
+    const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
+    const long n_pass = (unit1 - unit0) * nseg;
+    if (n_pass <= 0) return;
+
+    f32x2 acc[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+
+    const long first_tile = unit0 / A.n_src;
+    float *slab_wg = slab + (long)blockIdx.x * A.parts_per_wg * 2 * TILE;
+    const unsigned prio_flip = blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u;
+    const __amdgpu_buffer_rsrc_t tab =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packed), 0, (int)A.packed_bytes, 0x00020000);
+    const unsigned L4 = 4u * (unsigned)A.L;
+
+    auto flush = [&](long tile) {
+        float *dst = slab_wg + (tile - first_tile) * 2 * TILE + 2048 * wv + 32 * lane;
+        f32x4 *l4 = reinterpret_cast<f32x4 *>(dst);
+        f32x4 *r4 = reinterpret_cast<f32x4 *>(dst + TILE);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            l4[i] = f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x};
+            r4[i] = f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y};
+        }
+#pragma unroll
+        for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+    };
+
+    // scalar state of the walk over (tile, source, tap segment): advanced by counters, never re-divided
+    long tile = first_tile;
+    int s = (int)(unit0 - first_tile * A.n_src);
+    int sg = 0;
+    // window geometry, recomputed only when (tile, segment) changes
+    long geo_tile = -1;
+    int geo_sg = -1;
+    int seg0 = 0, Lseg = 0, halo = 0, nrows = 0, c0 = 0, mo0 = 0;
+    long xbase = 0;
+    // this wave's share of the chunk slots: [slot_a, slot_b), evaluating chunk IRs slot_a .. slot_b
+    const int slot_a = wv * A.spw;
+    const int slot_b = slot_a + A.spw < A.nslots ? slot_a + A.spw : A.nslots;
+    const int n_ev = slot_a < A.nslots ? slot_b - slot_a + 1 : 0;       // chunk IRs this wave evaluates per pass
+
+#ifdef BAS_STAMPS
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    for (long pid = 0; pid < n_pass; ++pid) {
+        FZ_STAMP_NW(t0);
+        if (tile != geo_tile || sg != geo_sg) {
+            if (tile != geo_tile && geo_tile >= 0) flush(geo_tile);
+            geo_tile = tile;
+            geo_sg = sg;
+            seg0 = sg * RT_SEG;
+            Lseg = A.Lp - seg0 < RT_SEG ? A.Lp - seg0 : RT_SEG;
+            halo = (Lseg + 31) >> 5;                         // input rows above the tile that matter
+            xbase = tile * TILE - seg0 - 32L * halo;         // first input sample in LDS (multiple of 32)
+            nrows = TILE / 32 + halo;
+            long cf = xbase / A.K;                           // floor division, consistent across 0
+            if (cf * A.K > xbase) --cf;
+            c0 = (int)cf;
+            mo0 = (int)(xbase - cf * A.K);
+        }
+
+        __builtin_amdgcn_s_setprio(3);                       // staging is latency bound: its few instructions go first
+        // ---- global -> registers: this wave's read plans (chunk IRs slot_a .. slot_b, both ears) and the x window
+        f32x4 pv[2];
+        {
+            const f32x4 *pl_src = reinterpret_cast<const f32x4 *>(plans) + (long)s * (A.n_chunks + 1) * PL4;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                int p = lane + 64 * r;                       // 16-byte piece of the wave's n_ev * 18
+                p = p < n_ev * PL4 ? p : 0;
+                const int i = (p * 3641) >> 16;              // p / 18 for p < 128
+                const int c = clampi(c0 + slot_a + i, 0, A.n_chunks);
+                pv[r] = pl_src[(long)c * PL4 + (p - i * PL4)];
+            }
+        }
+        const float *xwin = x + (long)s * A.x_stride + xbase;
+        const long lo_l = -xbase, hi_l = A.T_in - xbase;     // offsets of the signal's first sample / one past its last
+        const int x_lo = lo_l < -(1 << 30) ? -(1 << 30) : (lo_l > (1 << 30) ? (1 << 30) : (int)lo_l);
+        const int x_hi = hi_l < -(1 << 30) ? -(1 << 30) : (hi_l > (1 << 30) ? (1 << 30) : (int)hi_l);
+        const bool x_inside = x_lo <= 0 && x_hi >= 4 * NX * THREADS;   // whole window inside the signal
+        f32x4 xv[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            int i = 4 * (tid + j * THREADS);
+            i = i < x_lo ? x_lo : i;
+            i = i > x_hi - 4 ? x_hi - 4 : i;                 // clamped into the row (T_in is a multiple of K >= 32)
+            xv[j] = *reinterpret_cast<const f32x4 *>(xwin + i);
+        }
+        FZ_STAMP_NW(t1);
+        __syncthreads();                                     // previous pass has finished reading LDS
+        FZ_STAMP_NW(t2);
+
+        // ---- registers -> LDS: plans into this wave's own region, the x window as a column-major image
+        f32x4 *plw = reinterpret_cast<f32x4 *>(hd + A.nslots * HD_SLOT) + wv * (MAXEV * PL4);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            if (lane + 64 * r < n_ev * PL4) plw[lane + 64 * r] = pv[r];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const int i4 = tid + j * THREADS;
+            f32x4 v = xv[j];
+            if (!x_inside) {                                 // uniform: only windows that overlap an end of the signal
+                const int e = 4 * i4;                        // x_lo, x_hi are multiples of 4: all four in or out
+                if (!(e >= x_lo && e < x_hi)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (i4 < nrows * 8) xs4[(i4 & 7) * XR + (i4 >> 3)] = v;
+        }
+        __builtin_amdgcn_wave_barrier();                     // other lanes of this wave read the plan words below
+        FZ_STAMP(t3);
+
+        // ---- chunk IRs from the table: lanes 0-31 four adjacent taps of the left ear, lanes 32-63 of the right.
+        // Two halves of 8 reads are in flight at any time; slot i - 1 = (IR i-1, IR i - IR i-1) is stored as soon
+        // as IR i is known: both ears of two taps per 16-byte LDS write.
+        {
+            const int half = lane >> 5;
+            const int m = seg0 + 4 * (lane & 31);
+            const int m_c = m < A.L ? m : A.L - 1;           // idle lanes evaluate a valid tap and drop it
+            const unsigned m4 = 4u * (unsigned)m_c;
+            const f32x4 live = f32x4{m < A.L ? 1.f : 0.f, m + 1 < A.L ? 1.f : 0.f, m + 2 < A.L ? 1.f : 0.f,
+                                     m + 3 < A.L ? 1.f : 0.f};                 // taps >= L read as zero
+            const f32x4 *pl = plw + half * (BAS_PLANS_WORDS / 4);
+            const int tq = 4 * (lane & 31) + (lane < 32 ? 2 : 0);          // first of the two taps this lane stores
+            f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tq;
+            FzHalf ha, hb;
+            f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
+            fz_issue<0>(tab, pl, m4, L4, ha);                // (n_ev = 0: reads stale plan words of an idle wave:
+            const f32x4 *pl_last = pl + (n_ev > 0 ? n_ev - 1 : 0) * PL4;          //  in-range offsets, nothing stored)
+            // a real loop without branches in its body: the load counters then carry across iterations and each
+            // half is folded while the next one is in flight (the last iteration re-requests its own first half)
+            for (int i = 0; i < n_ev; ++i) {
+                const f32x4 *pl_next = pl + PL4 < pl_last ? pl + PL4 : pl_last;
+                fz_issue<1>(tab, pl, m4, L4, hb);
+                f32x4 h = fz_finish<0>(pl, ha, f32x4{0.f, 0.f, 0.f, 0.f});
+                fz_issue<0>(tab, pl_next, m4, L4, ha);
+                h = fz_finish<1>(pl, hb, h) * live;
+                // slot i - 1 = (IR i-1, IR i - IR i-1); iteration 0 writes scrap into slot 0, iteration 1 replaces it
+                f32x2 h0a, h0b, da, db;
+                fz_pair_ears(prev, h0a, h0b);
+                fz_pair_ears(h - prev, da, db);
+                if (tq < Lseg) {
+                    dst[0] = f32x4{h0a.x, h0a.y, da.x, da.y};
+                    dst[1] = f32x4{h0b.x, h0b.y, db.x, db.y};
+                }
+                if (i > 0) dst += HD_SLOT / 4;
+                prev = h;
+                pl = pl_next;
+            }
+        }
+        FZ_STAMP(t4);
+        __syncthreads();
+        FZ_STAMP_NW(t5);
+
+        // ---- FIR: input rows rho' = 0..halo above/at the lane's output row
+        const int row_out = 64 * wv + lane + halo;           // window row holding the lane's outputs
+        const int pos = mo0 + 32 * row_out;
+        int sl = (int)((float)pos * A.invK);                 // chunk slot of that row (float estimate, corrected)
+        int m_in = pos - sl * A.K;                           // offset of the row inside its chunk
+        if (m_in < 0) { m_in += A.K; sl -= 1; }
+        if (m_in >= A.K) { m_in -= A.K; sl += 1; }
+        const f32x4 *xrow = xs4 + row_out;
+        {   // fair time slicing between the two workgroups of a CU (see bas_render_hd_kernel)
+            const unsigned t = (unsigned)(__builtin_amdgcn_s_memrealtime() >> 12);
+            if ((t & 1u) ^ prio_flip) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        for (int rp = 0; rp <= halo; ++rp) {
+            float al[1];
+            if (A.s_pow2) {
+                al[0] = (float)(m_in & ~(A.S - 1)) * A.invK;
+            } else {                                         // any multiple of 32: m_in / S by float estimate, corrected
+                int q = (int)((float)m_in * A.invS);
+                const int r = m_in - q * A.S;
+                if (r < 0) q -= 1;
+                if (r >= A.S) q += 1;
+                al[0] = (float)(q * A.S) * A.invK;
+            }
+            unsigned mk = 0;                                 // octet i holds taps 32 rp - 32 + 8 i .. +7 of the segment
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t0 = 32 * rp - 32 + 8 * i;
+                if (t0 >= 0 && t0 < Lseg) mk |= 1u << i;
+            }
+            float xr[32];
+            fz_load_xrow<XR>(xr, xrow);
+            hd_row_step_x<1, false>(acc, xr, hd + sl * HD_SLOT + (32 * rp - 32) * 4, al, mk);
+            xrow -= 1;
+            m_in -= 32;
+            if (m_in < 0) {
+                m_in += A.K;
+                sl -= 1;
+            }
+        }
+
+        FZ_STAMP_NW(t6);
+        FZ_ADD(0, t0, t1); FZ_ADD(1, t1, t2); FZ_ADD(2, t2, t3); FZ_ADD(3, t3, t4); FZ_ADD(4, t4, t5); FZ_ADD(5, t5, t6);
+        // ---- next (tile, source, segment)
+        if (++sg == nseg) {
+            sg = 0;
+            if (++s == A.n_src) {
+                s = 0;
+                ++tile;
+            }
+        }
+    }
+    flush(geo_tile);
+#ifdef BAS_STAMPS
+    if (lane == 0 && blockIdx.x < 2048) {
+        unsigned long long *d = bas_fz_stamps + (blockIdx.x * 4 + wv) * 8;
+        for (int i = 0; i < 6; ++i) d[i] = st_acc[i];
+        d[6] = __builtin_amdgcn_s_memrealtime() - st_begin;
+        d[7] = (unsigned long long)n_pass;
+    }
+#endif
+}
+
+#ifdef BAS_STAMPS
+extern "C" int bas_debug_read_fz_stamps(unsigned long long *host, size_t count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(bas_fz_stamps), count * sizeof(unsigned long long));
+}
+#endif
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct FzPlan {
+    int nw;                    // waves per workgroup: 4, 2 or 1 (0: shape not served)
+    int tile, nslots, spw;
+    long n_tiles, units_total;
+    int n_wg, units_per_wg, parts_per_wg;
+    size_t lds_bytes, slab_bytes;
+};
+
+static int fz_slots(int nw, int K) {                         // chunk slots a window of this tile can touch
+    const int rows = 2048 * nw / 32 + HD_HALO;
+    return (K - 32 + 32 * (rows - 1)) / K + 1;
+}
+
+static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
+    FzPlan p = {};
+    if (n_src <= 0 || T_in <= 0 || K < 32 || K % 32 != 0 || S % 32 != 0 || K % S != 0 || L <= 0) return p;
+    if (fz_slots(4, K) > FZ_MAXSLOTS) return p;              // K >= 448 or so
+    const long T_out = T_in + L - 1;
+    const int cus = bas_device_cus();
+    // largest tile that still gives every workgroup slot of the chip a unit; scenes with few sources (one source
+    // x 10 s is 54 tiles of 8192) take smaller tiles and with them more, narrower workgroups
+    const int cand[3] = {4, 2, 1};
+    for (int ci = 0; ci < 3; ++ci) {
+        const int nw = cand[ci];
+        const int nslots = fz_slots(nw, K);
+        const int maxev = nw == 4 ? 6 : 7;
+        const int spw = (nslots + nw - 1) / nw;
+        if (spw + 1 > maxev) continue;
+        const int rows = 2048 * nw / 32 + HD_HALO;
+        const size_t lds = (size_t)(8 * (rows + 1) * 4 + nslots * HD_SLOT + nw * maxev * 2 * BAS_PLANS_WORDS) * sizeof(float);
+        long wg_per_cu = (long)(160 * 1024 / lds);
+        const long by_waves = 8 / nw;                        // two waves per SIMD (register budget of the row step)
+        if (wg_per_cu > by_waves) wg_per_cu = by_waves;
+        if (wg_per_cu < 1) continue;
+        const long slots = wg_per_cu * cus;
+        const long n_tiles = (T_out + 2048L * nw - 1) / (2048L * nw);
+        const long units = n_tiles * n_src;
+        if (units < slots && nw > 1) continue;               // not enough work for this tile: try a smaller one
+        p.nw = nw;
+        p.tile = 2048 * nw;
+        p.nslots = nslots;
+        p.spw = spw;
+        p.n_tiles = n_tiles;
+        p.units_total = units;
+        const long wg = units < slots ? units : slots;
+        p.units_per_wg = (int)((units + wg - 1) / wg);
+        p.n_wg = (int)((units + p.units_per_wg - 1) / p.units_per_wg);
+        p.parts_per_wg = (p.units_per_wg + n_src - 2) / n_src + 1;
+        p.lds_bytes = lds;
+        p.slab_bytes = (size_t)p.n_wg * p.parts_per_wg * 2 * p.tile * sizeof(float);
+        return p;
+    }
+    return p;
+}
+
+extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L) {
+    return fz_plan(n_src, T_in, K, S, L).nw ? 1 : 0;
+}
+
+extern "C" size_t bas_render_fused_workspace_bytes(int n_src, long T_in, int K, int S, int L) {
+    return fz_plan(n_src, T_in, K, S, L).slab_bytes + 16;
+}
+
+extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed, const void *plans,
+                                        int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y,
+                                        int accumulate, float *peak, void *ws, size_t ws_bytes,
+                                        bas_stream_t stream, void *ev_begin, void *ev_end) {
+    BAS_REQUIRE(y, BAS_E_NULL, "bas_render_mix_fused_f32: y is null");
+    BAS_REQUIRE(n_src >= 0 && T_in >= 0 && K > 0 && S > 0 && L > 0 && ndir > 0, BAS_E_SHAPE,
+                "bas_render_mix_fused_f32: need n_src>=0, T_in>=0, K,S,L,ndir>0 (n_src=%d T_in=%ld K=%d S=%d L=%d)",
+                n_src, T_in, K, S, L);
+    BAS_REQUIRE(U >= BAS_PLAN_MIN_U, BAS_E_SHAPE, "bas_render_mix_fused_f32: needs an upsampling factor >= %d (U=%d)",
+                BAS_PLAN_MIN_U, U);
+    BAS_REQUIRE(K % S == 0, BAS_E_SHAPE,
+                "bas_render_mix_fused_f32: subchunksize does not divide chunksize evenly (K=%d S=%d)", K, S);
+    BAS_REQUIRE(T_in % K == 0, BAS_E_SHAPE, "bas_render_mix_fused_f32: T_in (%ld) must be a multiple of K (%d)", T_in, K);
+    BAS_REQUIRE(T_in / K < (1L << 30), BAS_E_SHAPE, "bas_render_mix_fused_f32: too many chunks");
+    hipStream_t st = bas_stream(stream);
+    const long T_out = T_in + L - 1;
+    unsigned int *peak_bits = reinterpret_cast<unsigned int *>(peak);
+    if (peak) {
+        hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);
+        if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
+    const bool live = n_src > 0 && T_in > 0;
+    if (!live) {                                             // nothing to render: y = 0 (or untouched), peak = max|y|
+        if (!accumulate) {
+            hipError_t e = hipMemsetAsync(y, 0, (size_t)2 * T_out * sizeof(float), st);
+            if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+            return 0;
+        }
+        return peak ? bas_peak_normalize_f32(y, 2 * T_out, peak, 0, stream) : 0;
+    }
+    BAS_REQUIRE(x && packed && plans, BAS_E_NULL, "bas_render_mix_fused_f32: x, packed or plans is null");
+    BAS_REQUIRE(x_stride >= T_in, BAS_E_SHAPE, "bas_render_mix_fused_f32: x_stride < T_in");
+    BAS_REQUIRE(reinterpret_cast<uintptr_t>(plans) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
+                    x_stride % 4 == 0 && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
+                BAS_E_ALIGN, "bas_render_mix_fused_f32: x, plans and ws must be 16-byte aligned, x_stride a multiple of 4");
+    const FzPlan p = fz_plan(n_src, T_in, K, S, L);
+    BAS_REQUIRE(p.nw != 0, BAS_E_SHAPE,
+                "bas_render_mix_fused_f32: sizes not served by the fused kernel (bas_render_fused_supported); use "
+                "bas_interp2d_f32 + bas_render_mix_f32");
+    BAS_REQUIRE(p.units_total < (1L << 31) - 65536, BAS_E_SHAPE,
+                "bas_render_mix_fused_f32: %ld (tile, source) work units exceed 2^31: render in blocks", p.units_total);
+    BAS_REQUIRE(ws && ws_bytes >= p.slab_bytes, BAS_E_WORKSPACE,
+                "bas_render_mix_fused_f32: workspace of %zu bytes needed, %zu given", p.slab_bytes, ws_bytes);
+    const size_t table_bytes = (size_t)2 * ndir * U * BAS_PLANE(L) * sizeof(float);
+    BAS_REQUIRE(table_bytes < (1ul << 31), BAS_E_SHAPE, "bas_render_mix_fused_f32: table too large");
+    FzArgs A;
+    A.x_stride = x_stride; A.n_src = n_src; A.T_in = T_in;
+    A.K = K; A.S = S; A.L = L; A.Lp = (L + 7) & ~7; A.n_chunks = (int)(T_in / K);
+    A.s_pow2 = (S & (S - 1)) == 0;
+    A.invK = 1.0f / (float)K; A.invS = 1.0f / (float)S;
+    A.units_total = p.units_total; A.units_per_wg = p.units_per_wg; A.parts_per_wg = p.parts_per_wg;
+    A.nslots = p.nslots; A.spw = p.spw;
+    A.packed_bytes = (unsigned)table_bytes;
+    float *slab = reinterpret_cast<float *>(ws);
+    typedef void (*fz_fn)(FzArgs, const float *, float *, const float *, const unsigned *);
+    const fz_fn fn = p.nw == 4 ? bas_render_fz_kernel<4> : (p.nw == 2 ? bas_render_fz_kernel<2> : bas_render_fz_kernel<1>);
+    hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
+    if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    hipEvent_t eb = reinterpret_cast<hipEvent_t>(ev_begin), ee = reinterpret_cast<hipEvent_t>(ev_end);
+    if (eb) (void)hipEventRecord(eb, st);
+    hipLaunchKernelGGL(fn, dim3(p.n_wg), dim3(64 * p.nw), p.lds_bytes, st, A, x, slab, packed,
+                       reinterpret_cast<const unsigned *>(plans));
+    if (ee) (void)hipEventRecord(ee, st);
+    int rc = bas_check_launch("bas_render_mix_fused_f32(fz)");
+    if (rc) return rc;
+    return bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
+                                  peak_bits, st, "bas_render_mix_fused_f32(reduce)");
+}

@@ -17,6 +17,14 @@ int bas_check_launch(const char *what);
 
 static inline hipStream_t bas_stream(bas_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// host helpers shared by the FIR launchers (bas_render.hip)
+int bas_grid_for(long items, int cap);
+int bas_device_cus();                                  // CU count of the current device, cached
+hipError_t bas_allow_full_lds(const void *fn);         // dynamic-LDS limit of a kernel raised once per device
+int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per_wg, int parts_per_wg, int n_wg,
+                           long T_out, float *y, int accumulate, unsigned int *peak_bits, hipStream_t st,
+                           const char *what);
+
 #define BAS_REQUIRE(cond, code, ...) \
     do { if (!(cond)) return bas_fail((code), __VA_ARGS__); } while (0)
 

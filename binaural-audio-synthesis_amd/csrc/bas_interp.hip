@@ -184,12 +184,13 @@ __device__ __forceinline__ void ring_plan(RingPlan &rp, const double *__restrict
 // 16 loads off scalar bases and 16 FMAs with scalar weights.
 #define BAS_QB 16      // queries per workgroup
 
-// plan kernel: one thread per (query, ear)
+// plan kernel: one thread per (query, ear).  SCALAR: write the plan as EarPlanS (for bas_render_mix_fused_f32)
+template <bool SCALAR>
 __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__restrict__ diffs,
                                                                   const int32_t *__restrict__ idx,
                                                                   const double *__restrict__ w, int n,
                                                                   int ndir, int L, int U,
-                                                                  EarPlanW *__restrict__ plans) {
+                                                                  void *__restrict__ plans_out) {
     const long t = blockIdx.x * 256L + threadIdx.x;
     if (t >= 2L * n) return;
     const long q = t >> 1;
@@ -246,7 +247,29 @@ __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__
 #pragma unroll
         for (int j = 0; j < 3; ++j) pl.w[13 + j] = (float)((1.0 - at) * wbt[j]);
     }
-    plans[t] = pl;
+    if (SCALAR) {
+        EarPlanS ps;
+        const int nset[4] = {5, 4, 4, 3};
+        int k = 0;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const SetPlan &sp = pl.set[st];
+            ps.o4[st] = 4u * (unsigned)sp.o;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (j < nset[st]) {
+                    // read j <= ph0: plane ph0 - j; beyond: plane ph0 - j + U one sample earlier (bas_plan.h set_dot)
+                    const int pb = j <= sp.ph0 ? sp.base - j * BAS_PLANE(L) : sp.base + (U - j) * BAS_PLANE(L) - 1;
+                    ps.off[k] = 4u * (unsigned)pb;
+                    ps.w[k] = pl.w[k];
+                    ++k;
+                }
+            }
+        }
+        reinterpret_cast<EarPlanS *>(plans_out)[t] = ps;
+    } else {
+        reinterpret_cast<EarPlanW *>(plans_out)[t] = pl;
+    }
 }
 
 // eval kernel: one wave per (query, ear).  The 128-byte plan is fetched with ONE coalesced vector
@@ -340,8 +363,10 @@ __global__ __launch_bounds__(256) void bas_interp2d_generic_kernel(const float *
     }
 }
 
+static_assert(sizeof(EarPlanS) == 4 * BAS_PLANS_WORDS && sizeof(EarPlanS) >= sizeof(EarPlanW), "plan sizes");
+
 extern "C" size_t bas_interp2d_workspace_bytes(int n) {
-    return n > 0 ? (size_t)n * 2 * sizeof(EarPlanW) + 16 : 16;
+    return n > 0 ? (size_t)n * 2 * sizeof(EarPlanS) + 16 : 16;     // the larger of the two plan forms
 }
 
 extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double *w, int n, int ndir,
@@ -359,8 +384,8 @@ extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, co
                 BAS_E_WORKSPACE, "bas_interp2d_plan_f32: 16-byte aligned buffer of %zu bytes needed, %zu given",
                 bas_interp2d_workspace_bytes(n), plans_bytes);
     const long rows = 2L * n;
-    hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                       bas_stream(stream), diffs, idx, w, n, ndir, L, U, reinterpret_cast<EarPlanW *>(plans));
+    hipLaunchKernelGGL(bas_interp2d_plan_kernel<true>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       bas_stream(stream), diffs, idx, w, n, ndir, L, U, plans);
     return bas_check_launch("bas_interp2d_plan_f32");
 }
 
@@ -385,7 +410,7 @@ extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const 
                            w, (long)n, ndir, L, U, H);
         return bas_check_launch("bas_interp2d_f32(generic)");
     }
-    hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
+    hipLaunchKernelGGL(bas_interp2d_plan_kernel<false>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
                        w, n, ndir, L, U, plans);
     int rc = bas_check_launch("bas_interp2d_f32(plan)");
     if (rc) return rc;

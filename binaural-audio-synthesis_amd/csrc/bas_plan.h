@@ -23,6 +23,17 @@ struct EarPlanW {
     float w[16];       // same order as the sets: 5 + 4 + 4 + 3
 };
 
+// The same plan in the form the fused FIR kernel reads (bas_fused.hip): byte offsets instead of (plane, phase)
+// descriptors, so the evaluator has no per-read selection work left.  A wave stages the plans of its chunk IRs
+// in LDS and every lane picks up the values of ITS ear's plan with broadcast reads (16-byte LDS reads of one
+// address per half-wave): off[] and o4[] feed address adds, w[] packed FMAs.
+#define BAS_PLANS_WORDS 36
+struct EarPlanS {
+    unsigned off[16];  // byte offset into `packed` of read j's plane sample 0 (the -1 of a wrapped phase included)
+    float w[16];       // folded blend weights, same order (read sets of 5 + 4 + 4 + 3)
+    unsigned o4[4];    // 4 * o of the four read sets (bytes): lane offset = wrap(4 m + o4)
+};
+
 __device__ __forceinline__ void make_set(SetPlan &sp, int row, int c, int L, int U, int dir) {
     const int o = c / U, ph = c - o * U;           // c in [0, M)
     sp.base = row + ph * BAS_PLANE(L) + 1;

@@ -25,6 +25,7 @@
 // workgroups share a CU.  No MFMA: this is a 1-D FIR (BASELINE.json north_star).
 #include "bas_internal.h"
 #include "bas_plan.h"
+#include "bas_fir.h"
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -32,7 +33,6 @@
 
 #define RT_THREADS 256
 #define RT_TILE 2048            // outputs per tile: 64 lanes x 32
-#define RT_SEG 128              // taps per LDS pass
 #define RT_RS (2 * RT_SEG + 4)  // floats per IR row in LDS (+16 B: rows land on distinct banks)
 #define RT_ROWS (RT_TILE / 32 + RT_SEG / 32)      // 68
 #define RT_XR (RT_ROWS + 1)     // odd row count of the column-major x image (conflict-free stores)
@@ -53,10 +53,6 @@ struct RenderArgs {
 #ifdef BAS_DIAG
     int dbg;               // ablation flags (BAS_DEBUG_FLAGS; diagnostic build only, make diag)
 #endif
-    // fused path (chunk IRs evaluated from read plans inside the FIR kernel, H unused)
-    const float *packed;   // table in phase-plane layout
-    const int *plans;      // [n_src][n_chunks+1][2 ears][32 words]
-    int U;
 };
 
 // Ablation switches exist only in the diagnostic build (make diag / make stamps -> libbas_hip_diag.so,
@@ -89,10 +85,6 @@ __device__ __forceinline__ void win_load(Win &w, const float *__restrict__ p) {
         w.t[2 * i] = f32x2{v.x, v.y};
         w.t[2 * i + 1] = f32x2{v.z, v.w};
     }
-}
-
-__device__ __forceinline__ void fma2(f32x2 &acc, float xv, f32x2 g) {
-    acc = __builtin_elementwise_fma(g, f32x2{xv, xv}, acc);
 }
 
 // taps 0..7 of the segment (window lower half absent): k = r - a >= 0
@@ -175,8 +167,6 @@ struct Prefetch {
     f32x4 xv[RT_NX];
     f32x2 hl[RT_NH], hr[RT_NH];    // left / right ear, taps (2l, 2l+1)
 };
-
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 __device__ __forceinline__ void prefetch_h(Prefetch &F, const RenderArgs &A, const Pass &P, int c_first,
                                             int lane) {
@@ -420,16 +410,14 @@ __global__ __launch_bounds__(RT_THREADS, 2) void bas_render_rows32_kernel(Render
 //   NSUB   S = 16 / 8 / 4 with K a multiple of 32: a row holds 2 / 4 / 8 subchunks, each with its own formed taps
 //   HONLY  more than HD_MAXSLOTS chunk slots under a tile (K < 448): the slots hold (h_L, h_R) only
 //   DUAL   any other subchunk / chunk size: the row step runs once per part of a row (multi-part rows)
-//   FUSED  the chunk IRs are evaluated from the table while staging (bas_render_mix_fused_f32)
+// (The fused form - chunk IRs evaluated from the table while staging - is bas_render_fz_kernel, bas_fused.hip.)
 #define HD_NW 4                               // waves per workgroup: one per SIMD, so the CU stays balanced
 #define HD_THREADS (64 * HD_NW)
 #define HD_TILE (2048 * HD_NW)                // outputs per tile
-#define HD_HALO (RT_SEG / 32)                 // input rows above a tile (4)
 #define HD_ROWS (HD_TILE / 32 + HD_HALO)      // rows in the x window (260)
 #define HD_XR (HD_ROWS + 1)                   // odd: conflict-free column-major image
 #define HD_NX ((HD_ROWS * 8 + HD_THREADS - 1) / HD_THREADS)     // float4 of x per thread (9)
-#define HD_SLOT (RT_SEG * 4 + 4)              // floats per chunk slot (+16 B: slots on distinct banks)
-#define HD_MAXSLOTS 20                     // chunk slots for two workgroups per CU (and the fused staging)
+#define HD_MAXSLOTS 20                     // chunk slots for two workgroups per CU
 #define HD_HALFSLOTS (HD_MAXSLOTS / 2)     // chunk slots staged by one half of the threads
 #define HD_X_FLOATS (8 * HD_XR * 4)
 
@@ -439,85 +427,6 @@ __device__ __forceinline__ void hd_load_xrow(float (&xr)[32], const f32x4 *__res
         const f32x4 v = xrow[c * HD_XR];
         xr[4 * c] = v.x; xr[4 * c + 1] = v.y; xr[4 * c + 2] = v.z; xr[4 * c + 3] = v.w;
     }
-}
-
-#define HO_SLOT (RT_SEG * 2 + 2)             // floats per chunk slot of the h-only image (+8 B: slots on distinct banks)
-
-// HONLY: the slot holds (h_L, h_R) only and d = H_{c+1} - H_c is taken here from the next slot (small chunks:
-// twice as many chunk slots fit the LDS; one more packed op per tap)
-template <bool HONLY>
-__device__ __forceinline__ void hd_load_octet(f32x4 (&hv)[8], const float *__restrict__ hdrow, int i) {
-    if (HONLY) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const f32x2 h0 = *reinterpret_cast<const f32x2 *>(hdrow + (8 * i + j) * 2);
-            const f32x2 h1 = *reinterpret_cast<const f32x2 *>(hdrow + HO_SLOT + (8 * i + j) * 2);
-            const f32x2 d = h1 - h0;
-            hv[j] = f32x4{h0.x, h0.y, d.x, d.y};
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) hv[j] = *reinterpret_cast<const f32x4 *>(hdrow + (8 * i + j) * 4);
-    }
-}
-
-// one octet of taps (delta = 8 i + j - 32 = output index - input index) against the whole input row.
-// NSUB > 1: the subchunk is shorter than a row (S = 32 / NSUB), so the row's 32 inputs fall into NSUB
-// groups with their own crossfade weight al[u]; each group gets its own formed taps.
-template <int I, int NSUB>
-__device__ __forceinline__ void hd_octet_fma(f32x2 (&acc)[32], const float (&xr)[32], const f32x4 (&hv)[8],
-                                              const float (&al)[NSUB]) {
-    constexpr int G = 32 / NSUB;                 // inputs per group (= the subchunk size when NSUB > 1)
-    if constexpr (NSUB <= 4) {                   // few groups: all their taps formed up front
-        f32x2 g[NSUB][8];
-#pragma unroll
-        for (int u = 0; u < NSUB; ++u)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                g[u][j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al[u], al[u]},
-                                                    f32x2{hv[j].x, hv[j].y});
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int delta = 8 * I + j - 32;
-#pragma unroll
-            for (int o = 0; o < 32; ++o) {
-                const int a = o - delta;
-                if (a >= 0 && a < 32) fma2(acc[o], xr[a], g[a / G][j]);
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int u = 0; u < NSUB; ++u) {             // many groups: one at a time, eight formed taps live
-        f32x2 g[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-            g[j] = __builtin_elementwise_fma(f32x2{hv[j].z, hv[j].w}, f32x2{al[u], al[u]}, f32x2{hv[j].x, hv[j].y});
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int delta = 8 * I + j - 32;
-#pragma unroll
-            for (int o = 0; o < 32; ++o) {
-                const int a = o - delta;
-                if (a >= u * G && a < (u + 1) * G && a >= 0 && a < 32) fma2(acc[o], xr[a], g[j]);
-            }
-        }
-    }
-}
-
-// Row step on an x row already in registers, with a run-time set of live octets.
-template <int NSUB, bool HONLY>
-__device__ __forceinline__ void hd_row_step_x(f32x2 (&acc)[32], const float (&xr)[32], const float *__restrict__ hdrow,
-                                               const float (&al)[NSUB], unsigned live_mask) {
-    f32x4 hv[8];
-#define HD_MASKED_OCTET(I)                          \
-    if (live_mask & (1u << I)) {                    \
-        hd_load_octet<HONLY>(hv, hdrow, I);         \
-        hd_octet_fma<I, NSUB>(acc, xr, hv, al);     \
-    }
-    HD_MASKED_OCTET(0) HD_MASKED_OCTET(1) HD_MASKED_OCTET(2) HD_MASKED_OCTET(3)
-    HD_MASKED_OCTET(4) HD_MASKED_OCTET(5) HD_MASKED_OCTET(6) HD_MASKED_OCTET(7)
-#undef HD_MASKED_OCTET
 }
 
 // Row step with a run-time set of live octets (segments shorter than 128 taps, last row).
@@ -534,10 +443,9 @@ __device__ __forceinline__ void hd_row_step_masked(f32x2 (&acc)[32], const f32x4
 // at inputs that differ from lane to lane: the row step runs once per part of the row, on that part's inputs
 // (the others zeroed) with its (slot, alpha) - two parts for subchunks >= 32 (twice the FMAs), up to
 // ceil(32 / S) + 1 below that; still far ahead of the generic kernel.
-template <bool FUSED, int NSUB, bool HONLY = false, bool DUAL = false>
+template <int NSUB, bool HONLY = false, bool DUAL = false>
 __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs A, int nslots) {
-    static_assert(!(FUSED && HONLY), "the h-only image is staged from H");
-    static_assert(!DUAL || (NSUB == 1 && !FUSED), "multi-part rows: one alpha per part, unfused");
+    static_assert(!DUAL || NSUB == 1, "multi-part rows: one alpha per part");
     extern __shared__ f32x4 lds4[];
     f32x4 *xs4 = lds4;                                       // [8][HD_XR] float4
     float *hd = reinterpret_cast<float *>(lds4) + HD_X_FLOATS;   // [nslots][HD_SLOT]
@@ -622,9 +530,7 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             i = i > x_hi4 - 4 ? x_hi4 - 4 : i;               // clamped into the row (x_hi4 - 4 >= x_lo as T_in >= 1)
             xv[j] = *reinterpret_cast<const f32x4 *>(xwin + i);
         }
-        // chunk IRs.  Unfused: thread = (tap, half), each half of the threads stages half of the chunk
-        // slots from H.  Fused: wave wv evaluates rows (slot, ear) = wv, wv+4, .. of the nslots+1 chunk
-        // IRs straight from the table through their read plans (one 128-byte plan per row, fetched now).
+        // chunk IRs: thread = (tap, half), each half of the threads stages half of the chunk slots from H
         const int tap = tid & (RT_SEG - 1);
         // (h0, d) image: a half stages slots [slot_a, slot_b) and needs H of slot_b too; h-only image: a half
         // stages the H values [slot_a, slot_b] of the nslots + 1 chunk boundaries (slot_b inclusive = last - 1 + 1)
@@ -634,29 +540,15 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         if (HONLY) slot_b -= 1;                               // inclusive end of the values this half loads
         if (slot_b > nslots) slot_b = nslots;
         f32x2 hlr[HD_HALFSLOTS + 1];                         // (left, right) tap of the slots this thread stages
-        constexpr int HD_MAXEVAL = (HD_MAXSLOTS + 1 + HD_NW - 1) / HD_NW;           // chunk IRs per wave
-        int pword[HD_MAXEVAL];
-        const int n_hslots = nslots + 1;                     // chunk IRs this pass needs
-        if (FUSED) {
-            // wave wv evaluates chunk IRs wv, wv+4, ..: lanes 0-31 the left ear, lanes 32-63 the right
-            const int *pl = A.plans + ((long)s * (A.n_chunks + 1)) * 64 + lane;    // 64 words per chunk: L|R plans
+        int k = seg0 + tap;
+        if (k > A.L - 1) k = A.L - 1;
+        const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
 #pragma unroll
-            for (int i = 0; i < HD_MAXEVAL; ++i) {
-                int sl_i = wv + HD_NW * i;
-                if (sl_i > n_hslots - 1) sl_i = n_hslots - 1;    // clamped: no branch around the load
-                pword[i] = pl[(long)clampi(c0 + sl_i, 0, A.n_chunks) * 64];
-            }
-        } else {
-            int k = seg0 + tap;
-            if (k > A.L - 1) k = A.L - 1;
-            const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
-#pragma unroll
-            for (int j = 0; j <= HD_HALFSLOTS; ++j) {
-                if (slot_a + j <= slot_b) {                  // uniform per wave
-                    const float *p = Hk + (long)clampi(c0 + slot_a + j, 0, A.n_chunks) * 2 * A.L;
-                    hlr[j].x = p[0];
-                    hlr[j].y = p[A.L];
-                }
+        for (int j = 0; j <= HD_HALFSLOTS; ++j) {
+            if (slot_a + j <= slot_b) {                  // uniform per wave
+                const float *p = Hk + (long)clampi(c0 + slot_a + j, 0, A.n_chunks) * 2 * A.L;
+                hlr[j].x = p[0];
+                hlr[j].y = p[A.L];
             }
         }
 
@@ -676,84 +568,46 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
             }
             if (i4 < nrows * 8) xs4[(i4 & 7) * HD_XR + (i4 >> 3)] = v;
         }
-        if (FUSED) {
-            // interpolate_2d for the chunk IRs of this pass (apply_hrtf.py:219-279), taps seg0 .. seg0+Lseg:
-            // a lane owns four adjacent taps of one ear (16-byte table loads); h goes to (h0_L | h0_R)
-            const int half = lane >> 5;
-            const int mt = 4 * (lane & 31);                  // tap inside the segment
-            const int m = seg0 + mt;
-            const int m_c = m < A.L ? m : A.L - 1;
-            const int n_iter = (n_hslots + HD_NW - 1) / HD_NW;
+        const bool beyond = seg0 + tap >= A.L;           // taps >= L read as zero (only when L % 8 != 0)
+        f32x2 *dst = reinterpret_cast<f32x2 *>(hd) + (HONLY ? slot_a * (HO_SLOT / 2) + tap
+                                                             : 2 * (slot_a * (HD_SLOT / 4) + tap));
+        if (HONLY) {
+            // h-only image: plain copies of the H values slot_a .. slot_b, rounds of HD_HALFSLOTS + 1
+            if (tap < Lseg) {
 #pragma unroll
-            for (int i = 0; i < HD_MAXEVAL; ++i) {
-                if (i < n_iter) {                            // uniform
-                    int sl_i = wv + HD_NW * i;
-                    if (sl_i > n_hslots - 1) sl_i = n_hslots - 1;
-                    f32x4 h = plan_eval_quad(A.packed, pword[i], half, m_c, A.L, A.U);
-                    if (m + 3 >= A.L) {                      // taps >= L read as zero
-                        if (m >= A.L) h.x = 0.f;
-                        if (m + 1 >= A.L) h.y = 0.f;
-                        if (m + 2 >= A.L) h.z = 0.f;
-                        h.w = 0.f;
-                    }
-                    if (mt < Lseg) {
-                        float *dst = hd + sl_i * HD_SLOT + 4 * mt + half;
-                        dst[0] = h.x; dst[4] = h.y; dst[8] = h.z; dst[12] = h.w;
+                for (int j = 0; j <= HD_HALFSLOTS; ++j)
+                    if (slot_a + j <= slot_b) dst[j * (HO_SLOT / 2)] = beyond ? f32x2{0.f, 0.f} : hlr[j];
+            }
+            constexpr int XH = 6;
+            for (int base = HD_HALFSLOTS + 1; slot_a + base <= slot_b; base += XH) {      // uniform per wave
+                int k = seg0 + tap;
+                if (k > A.L - 1) k = A.L - 1;
+                const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
+                f32x2 more[XH];
+#pragma unroll
+                for (int j = 0; j < XH; ++j) {
+                    if (slot_a + base + j <= slot_b) {
+                        const float *p = Hk + (long)clampi(c0 + slot_a + base + j, 0, A.n_chunks) * 2 * A.L;
+                        more[j].x = beyond ? 0.f : p[0];
+                        more[j].y = beyond ? 0.f : p[A.L];
                     }
                 }
-            }
-            __syncthreads();
-            // d = H_{c+1} - H_c next to h0 (slot nslots only lends its h0)
-            for (int i = tid; i < nslots * RT_SEG; i += HD_THREADS) {
-                const int slot = i >> 7, t = i & (RT_SEG - 1);
-                if (t < Lseg) {
-                    f32x4 *p4 = reinterpret_cast<f32x4 *>(hd) + slot * (HD_SLOT / 4) + t;
-                    const f32x4 a = p4[0], b = p4[HD_SLOT / 4];
-                    reinterpret_cast<f32x2 *>(p4)[1] = f32x2{b.x - a.x, b.y - a.y};
-                }
-            }
-        } else {
-            const bool beyond = seg0 + tap >= A.L;           // taps >= L read as zero (only when L % 8 != 0)
-            f32x2 *dst = reinterpret_cast<f32x2 *>(hd) + (HONLY ? slot_a * (HO_SLOT / 2) + tap
-                                                                 : 2 * (slot_a * (HD_SLOT / 4) + tap));
-            if (HONLY) {
-                // h-only image: plain copies of the H values slot_a .. slot_b, rounds of HD_HALFSLOTS + 1
                 if (tap < Lseg) {
 #pragma unroll
-                    for (int j = 0; j <= HD_HALFSLOTS; ++j)
-                        if (slot_a + j <= slot_b) dst[j * (HO_SLOT / 2)] = beyond ? f32x2{0.f, 0.f} : hlr[j];
+                    for (int j = 0; j < XH; ++j)
+                        if (slot_a + base + j <= slot_b) dst[(base + j) * (HO_SLOT / 2)] = more[j];
                 }
-                constexpr int XH = 6;
-                for (int base = HD_HALFSLOTS + 1; slot_a + base <= slot_b; base += XH) {      // uniform per wave
-                    int k = seg0 + tap;
-                    if (k > A.L - 1) k = A.L - 1;
-                    const float *Hk = A.H + ((long)s * (A.n_chunks + 1)) * 2 * A.L + k;
-                    f32x2 more[XH];
+            }
+        } else if (tap < Lseg) {
+            if (beyond) {
 #pragma unroll
-                    for (int j = 0; j < XH; ++j) {
-                        if (slot_a + base + j <= slot_b) {
-                            const float *p = Hk + (long)clampi(c0 + slot_a + base + j, 0, A.n_chunks) * 2 * A.L;
-                            more[j].x = beyond ? 0.f : p[0];
-                            more[j].y = beyond ? 0.f : p[A.L];
-                        }
-                    }
-                    if (tap < Lseg) {
+                for (int j = 0; j <= HD_HALFSLOTS; ++j) hlr[j] = f32x2{0.f, 0.f};
+            }
 #pragma unroll
-                        for (int j = 0; j < XH; ++j)
-                            if (slot_a + base + j <= slot_b) dst[(base + j) * (HO_SLOT / 2)] = more[j];
-                    }
-                }
-            } else if (tap < Lseg) {
-                if (beyond) {
-#pragma unroll
-                    for (int j = 0; j <= HD_HALFSLOTS; ++j) hlr[j] = f32x2{0.f, 0.f};
-                }
-#pragma unroll
-                for (int j = 0; j < HD_HALFSLOTS; ++j) {
-                    if (slot_a + j < slot_b) {               // (h0_L, h0_R | d_L, d_R): two 8-byte halves, no repacking
-                        dst[j * (HD_SLOT / 2)] = hlr[j];
-                        dst[j * (HD_SLOT / 2) + 1] = hlr[j + 1] - hlr[j];
-                    }
+            for (int j = 0; j < HD_HALFSLOTS; ++j) {
+                if (slot_a + j < slot_b) {               // (h0_L, h0_R | d_L, d_R): two 8-byte halves, no repacking
+                    dst[j * (HD_SLOT / 2)] = hlr[j];
+                    dst[j * (HD_SLOT / 2) + 1] = hlr[j + 1] - hlr[j];
                 }
             }
         }
@@ -1002,7 +856,7 @@ __global__ __launch_bounds__(256) void bas_mix_partials_kernel(const float *__re
     }
 }
 
-static int grid_for(long items, int cap) {
+int bas_grid_for(long items, int cap) {
     long g = (items + 255) / 256;
     if (g < 1) g = 1;
     return (int)(g < cap ? g : cap);
@@ -1022,7 +876,7 @@ static int current_device() {
     return dev;
 }
 
-static int device_cus() {
+int bas_device_cus() {
     const int dev = current_device();
     const bool cached = dev >= 0 && dev < BAS_MAX_DEVICES;
     int cus = cached ? g_cus[dev].load(std::memory_order_relaxed) : 0;
@@ -1036,7 +890,7 @@ static int device_cus() {
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize, raised once per (kernel, device) to the whole LDS
-static hipError_t allow_full_lds(const void *fn) {
+hipError_t bas_allow_full_lds(const void *fn) {
     static std::mutex mu;
     static struct { const void *fn; unsigned long long devs; } seen[64];
     static int n_seen = 0;
@@ -1056,6 +910,15 @@ static hipError_t allow_full_lds(const void *fn) {
     }
     if (slot >= 0) seen[slot].devs |= bit;
     return hipSuccess;
+}
+
+// slabs of partial tiles -> y (fixed order), fused max|y|: shared by the FIR launchers (bas_fused.hip too)
+int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per_wg, int parts_per_wg, int n_wg,
+                           long T_out, float *y, int accumulate, unsigned int *peak_bits, hipStream_t st,
+                           const char *what) {
+    hipLaunchKernelGGL(bas_slab_reduce_kernel, dim3(bas_grid_for((T_out + 3) / 4, 2048)), dim3(256), 0, st, slab, tile,
+                       n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits);
+    return bas_check_launch(what);
 }
 
 enum { KIND_GENERIC = 0, KIND_ROWS32 = 1, KIND_HD = 2 };
@@ -1105,7 +968,7 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
         const long T_out = T_in + L - 1;
         p.n_tiles = (T_out + p.tile - 1) / p.tile;
         p.units_total = p.n_tiles * n_src;
-        long slots = wg_per_cu * device_cus();
+        long slots = wg_per_cu * bas_device_cus();
         long wg = p.units_total < slots ? p.units_total : slots;
         p.units_per_wg = (int)((p.units_total + wg - 1) / wg);
         p.n_wg = (int)((p.units_total + p.units_per_wg - 1) / p.units_per_wg);
@@ -1131,7 +994,7 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
         p.hd_slots = hd_slots;
         p.honly = hd_slots > HD_MAXSLOTS;                   // measured faster than the full image at one workgroup per CU
         p.lds_bytes = p.honly ? (size_t)(HD_X_FLOATS + (hd_slots + 1) * HO_SLOT) * sizeof(float)
-                              : (size_t)(HD_X_FLOATS + (hd_slots + 1) * HD_SLOT) * sizeof(float);   // +1: fused h0 of the last chunk
+                              : (size_t)(HD_X_FLOATS + (hd_slots + 1) * HD_SLOT) * sizeof(float);
         wg_per_cu = (long)(160 * 1024 / p.lds_bytes);
         if (wg_per_cu > 2) wg_per_cu = 2;
         if (wg_per_cu < 1) wg_per_cu = 1;
@@ -1144,7 +1007,7 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
     const long T_out = T_in + L - 1;
     p.n_tiles = (T_out + p.tile - 1) / p.tile;
     p.units_total = p.n_tiles * n_src;
-    long slots = wg_per_cu * device_cus();
+    long slots = wg_per_cu * bas_device_cus();
     long wg = p.units_total < slots ? p.units_total : slots;
     p.units_per_wg = (int)((p.units_total + wg - 1) / wg);
     p.n_wg = (int)((p.units_total + p.units_per_wg - 1) / p.units_per_wg);
@@ -1165,7 +1028,7 @@ extern "C" size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S,
         q.tile = RT_TILE;
         q.n_tiles = (T_out + RT_TILE - 1) / RT_TILE;
         q.units_total = q.n_tiles * n_src;
-        long slots = 2L * device_cus();
+        long slots = 2L * bas_device_cus();
         long wg = q.units_total < slots ? q.units_total : slots;
         q.units_per_wg = (int)((q.units_total + wg - 1) / wg);
         q.n_wg = (int)((q.units_total + q.units_per_wg - 1) / q.units_per_wg);
@@ -1185,9 +1048,7 @@ extern "C" const char *bas_render_kernel_name(int n_src, long T_in, int K, int S
 
 static int render_mix_impl(const float *x, long x_stride, const float *H, int n_src, long T_in, int K, int S,
                            int L, float *y, int accumulate, float *peak, void *ws, size_t ws_bytes,
-                           bas_stream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end,
-                           const float *packed = nullptr, const void *plans = nullptr, int U = 0) {
-    const bool fused = packed != nullptr;
+                           bas_stream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
     BAS_REQUIRE(y, BAS_E_NULL, "bas_render_mix_f32: y is null");
     BAS_REQUIRE(n_src >= 0 && T_in >= 0 && K > 0 && S > 0 && L > 0, BAS_E_SHAPE,
                 "bas_render_mix_f32: need n_src>=0, T_in>=0, K,S,L>0 (n_src=%d T_in=%ld K=%d S=%d L=%d)",
@@ -1196,8 +1057,7 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
                 "bas_render_mix_f32: subchunksize does not divide chunksize evenly (K=%d S=%d)", K, S);
     BAS_REQUIRE(T_in % K == 0, BAS_E_SHAPE, "bas_render_mix_f32: T_in (%ld) must be a multiple of K (%d)", T_in,
                 K);
-    BAS_REQUIRE(n_src == 0 || T_in == 0 || (x && (H || (packed && plans))), BAS_E_NULL,
-                "bas_render_mix_f32: x or H (fused: packed, plans) is null");
+    BAS_REQUIRE(n_src == 0 || T_in == 0 || (x && H), BAS_E_NULL, "bas_render_mix_f32: x or H is null");
     BAS_REQUIRE(n_src == 0 || x_stride >= T_in, BAS_E_SHAPE, "bas_render_mix_f32: x_stride < T_in");
     BAS_REQUIRE(T_in / K < (1L << 30), BAS_E_SHAPE, "bas_render_mix_f32: too many chunks");
     hipStream_t st = bas_stream(stream);
@@ -1210,15 +1070,11 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     const int n_chunks = (int)(T_in / K);
     const bool aligned = (reinterpret_cast<uintptr_t>(x) % 16 == 0) && (x_stride % 4 == 0) &&
                          (reinterpret_cast<uintptr_t>(ws) % 16 == 0) && (reinterpret_cast<uintptr_t>(H) % 8 == 0);
-    (void)fused;
     const int live_src = T_in == 0 ? 0 : n_src;
     RenderPlan p = plan_render(live_src, T_in, K, S, L, aligned);
-    BAS_REQUIRE(!fused || live_src == 0 || (p.kind == KIND_HD && p.hd_slots <= HD_MAXSLOTS && !p.dual), BAS_E_SHAPE,
-                "bas_render_mix_fused_f32: sizes/alignment not served by the fused kernel "
-                "(bas_render_fused_supported); use bas_interp2d_f32 + bas_render_mix_f32");
     if (p.kind == KIND_GENERIC) {
         if (ev_begin) (void)hipEventRecord(ev_begin, st);
-        hipLaunchKernelGGL(bas_render_generic_kernel, dim3(grid_for(T_out, 8192)), dim3(256), 0, st, x, x_stride,
+        hipLaunchKernelGGL(bas_render_generic_kernel, dim3(bas_grid_for(T_out, 8192)), dim3(256), 0, st, x, x_stride,
                            H, live_src, T_in, K, S, L, n_chunks, T_out, y, accumulate, peak_bits);
         if (ev_end) (void)hipEventRecord(ev_end, st);
         return bas_check_launch("bas_render_mix_f32(generic)");
@@ -1235,26 +1091,24 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
 #ifdef BAS_DIAG
     { const char *d = getenv("BAS_DEBUG_FLAGS"); A.dbg = d ? atoi(d) : 0; }
 #endif
-    A.packed = packed; A.plans = reinterpret_cast<const int *>(plans); A.U = U;
     const int nsub = S >= 32 ? 1 : 32 / S;
-    BAS_REQUIRE(!fused || nsub == 1, BAS_E_SHAPE, "bas_render_mix_fused_f32: subchunks shorter than 32 are not fused");
     typedef void (*hd_fn)(RenderArgs, int);
     auto pick = [&](bool honly) -> hd_fn {
         switch (nsub) {
-        case 1: return honly ? bas_render_hd_kernel<false, 1, true> : bas_render_hd_kernel<false, 1>;
-        case 2: return honly ? bas_render_hd_kernel<false, 2, true> : bas_render_hd_kernel<false, 2>;
-        case 4: return honly ? bas_render_hd_kernel<false, 4, true> : bas_render_hd_kernel<false, 4>;
-        default: return honly ? bas_render_hd_kernel<false, 8, true> : bas_render_hd_kernel<false, 8>;
+        case 1: return honly ? bas_render_hd_kernel<1, true> : bas_render_hd_kernel<1>;
+        case 2: return honly ? bas_render_hd_kernel<2, true> : bas_render_hd_kernel<2>;
+        case 4: return honly ? bas_render_hd_kernel<4, true> : bas_render_hd_kernel<4>;
+        default: return honly ? bas_render_hd_kernel<8, true> : bas_render_hd_kernel<8>;
         }
     };
-    hd_fn hdk = fused ? bas_render_hd_kernel<true, 1> : pick(false);
+    hd_fn hdk = pick(false);
     if (p.kind == KIND_HD && p.dual)
-        hdk = p.honly ? bas_render_hd_kernel<false, 1, true, true> : bas_render_hd_kernel<false, 1, false, true>;
+        hdk = p.honly ? bas_render_hd_kernel<1, true, true> : bas_render_hd_kernel<1, false, true>;
     else if (p.kind == KIND_HD && p.honly)
         hdk = pick(true);
     const void *fn = p.kind == KIND_HD ? reinterpret_cast<const void *>(hdk)
                                         : reinterpret_cast<const void *>(bas_render_rows32_kernel);
-    hipError_t e = allow_full_lds(fn);
+    hipError_t e = bas_allow_full_lds(fn);
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
     if (p.kind == KIND_HD)
@@ -1264,10 +1118,8 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     if (ev_end) (void)hipEventRecord(ev_end, st);
     int rc = bas_check_launch(p.kind == KIND_HD ? "bas_render_mix_f32(hd)" : "bas_render_mix_f32(rows32)");
     if (rc) return rc;
-    hipLaunchKernelGGL(bas_slab_reduce_kernel, dim3(grid_for((T_out + 3) / 4, 2048)), dim3(256), 0, st,
-                       A.slab, p.tile, live_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
-                       peak_bits);
-    return bas_check_launch("bas_render_mix_f32(reduce)");
+    return bas_launch_slab_reduce(A.slab, p.tile, live_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
+                                  peak_bits, st, "bas_render_mix_f32(reduce)");
 }
 
 extern "C" int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,
@@ -1285,26 +1137,6 @@ extern "C" int bas_render_mix_profiled_f32(const float *x, long x_stride, const 
                            reinterpret_cast<hipEvent_t>(ev_begin), reinterpret_cast<hipEvent_t>(ev_end));
 }
 
-extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L) {
-    if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return 0;
-    const RenderPlan p = plan_render(n_src, T_in, K, S, L, true);
-    return (S >= 32 && p.kind == KIND_HD && p.hd_slots <= HD_MAXSLOTS && !p.dual) ? 1 : 0;
-}
-
-extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed, const void *plans,
-                                        int n_src, long T_in, int K, int S, int L, int U, float *y,
-                                        int accumulate, float *peak, void *ws, size_t ws_bytes,
-                                        bas_stream_t stream, void *ev_begin, void *ev_end) {
-    BAS_REQUIRE(packed && plans, BAS_E_NULL, "bas_render_mix_fused_f32: packed or plans is null");
-    BAS_REQUIRE(U >= BAS_PLAN_MIN_U, BAS_E_SHAPE, "bas_render_mix_fused_f32: needs an upsampling factor >= %d (U=%d)",
-                BAS_PLAN_MIN_U, U);
-    BAS_REQUIRE(reinterpret_cast<uintptr_t>(plans) % 16 == 0, BAS_E_ALIGN,
-                "bas_render_mix_fused_f32: plans must be 16-byte aligned");
-    return render_mix_impl(x, x_stride, nullptr, n_src, T_in, K, S, L, y, accumulate, peak, ws, ws_bytes, stream,
-                           reinterpret_cast<hipEvent_t>(ev_begin), reinterpret_cast<hipEvent_t>(ev_end), packed,
-                           plans, U);
-}
-
 extern "C" int bas_peak_normalize_f32(float *y, long n, float *peak, int apply, bas_stream_t stream) {
     BAS_REQUIRE(y || n == 0, BAS_E_NULL, "bas_peak_normalize_f32: y is null");
     BAS_REQUIRE(peak, BAS_E_NULL, "bas_peak_normalize_f32: peak (device float) is null");
@@ -1313,7 +1145,7 @@ extern "C" int bas_peak_normalize_f32(float *y, long n, float *peak, int apply, 
     hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);
     if (e != hipSuccess) return bas_fail((int)e, "bas_peak_normalize_f32: hipMemsetAsync: %s", hipGetErrorString(e));
     if (n == 0) return 0;
-    hipLaunchKernelGGL(bas_absmax_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, y, n,
+    hipLaunchKernelGGL(bas_absmax_kernel, dim3(bas_grid_for(n, 2048)), dim3(256), 0, st, y, n,
                        reinterpret_cast<unsigned int *>(peak));
     int rc = bas_check_launch("bas_peak_normalize_f32(absmax)");
     if (rc || !apply) return rc;
@@ -1324,7 +1156,7 @@ extern "C" int bas_scale_by_peak_f32(float *y, long n, const float *peak, bas_st
     BAS_REQUIRE(peak && (y || n == 0), BAS_E_NULL, "bas_scale_by_peak_f32: null pointer");
     BAS_REQUIRE(n >= 0, BAS_E_SHAPE, "bas_scale_by_peak_f32: n < 0");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(bas_scale_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, bas_stream(stream), y, n, peak);
+    hipLaunchKernelGGL(bas_scale_kernel, dim3(bas_grid_for(n, 2048)), dim3(256), 0, bas_stream(stream), y, n, peak);
     return bas_check_launch("bas_scale_by_peak_f32");
 }
 
@@ -1340,7 +1172,7 @@ extern "C" int bas_mix_partials_f32(const float *parts, int n_parts, long part_s
         if (e != hipSuccess) return bas_fail((int)e, "bas_mix_partials_f32: hipMemsetAsync: %s", hipGetErrorString(e));
     }
     if (n == 0) return 0;
-    hipLaunchKernelGGL(bas_mix_partials_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, parts, n_parts,
+    hipLaunchKernelGGL(bas_mix_partials_kernel, dim3(bas_grid_for(n, 2048)), dim3(256), 0, st, parts, n_parts,
                        part_stride, n, y, reinterpret_cast<unsigned int *>(peak));
     return bas_check_launch("bas_mix_partials_f32");
 }

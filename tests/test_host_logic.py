@@ -62,7 +62,7 @@ def test_library_exports_every_declared_symbol():
     lib = bas._hip.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.bas_version() == 1
+    assert lib.bas_version() == 2
     assert lib.bas_last_error() == b""
 
 
@@ -109,7 +109,7 @@ def test_diagnostic_build_is_separate_and_only_it_reads_the_environment():
     """libbas_hip_diag.so (-DBAS_DIAG) exports the same ABI; the shipped library contains neither hook string."""
     hip = bas._hip
     with hip.use_library(hip.DIAG_LIB_PATH) as diag:
-        assert hip.lib() is diag and diag.bas_version() == 1
+        assert hip.lib() is diag and diag.bas_version() == 2
     assert hip.lib() is not diag
     shipped = open(hip.LIB_PATH, "rb").read()
     assert b"BAS_FORCE_KERNEL" not in shipped and b"BAS_DEBUG_FLAGS" not in shipped
@@ -130,7 +130,7 @@ def test_small_upsampling_factor_is_refused_by_the_planned_entry_points():
             hip.call("bas_interp2d_plan_f32", a, a, a, 1, 187, 64, u, a, 4000, None)
         assert err.value.code == -2 and "upsampling" in str(err.value)
         with pytest.raises(hip.BasError) as err:
-            hip.call("bas_render_mix_fused_f32", a, 512, a, a, 1, 512, 512, 32, 64, u, a, 0, None, a, 4000, None, None, None)
+            hip.call("bas_render_mix_fused_f32", a, 512, a, a, 1, 512, 512, 32, 64, u, 187, a, 0, None, a, 4000, None, None, None)
         assert err.value.code == -2 and "upsampling" in str(err.value)
 
 
