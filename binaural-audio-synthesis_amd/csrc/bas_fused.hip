@@ -24,6 +24,7 @@
 #include "bas_internal.h"
 #include "bas_plan.h"
 #include "bas_fir.h"
+#include <stdlib.h>
 
 #ifdef BAS_STAMPS
 // Diagnostic build only (make stamps): per-wave totals of the pass phases in 10 ns ticks (s_memrealtime).
@@ -37,6 +38,18 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #define FZ_ADD(slot, a, b)
 #endif
 
+#ifndef FZ_PIPE_FULL
+#define FZ_PIPE_FULL 0        // chunk-IR evaluation: 1 = two whole IRs (32 table reads) in flight, 0 = two halves (16)
+#endif
+#ifndef FZ_STAGE_PRIO
+#define FZ_STAGE_PRIO 3         // wave priority while staging (0: leave it alone)
+#endif
+#ifndef FZ_SLICE_SHIFT
+#define FZ_SLICE_SHIFT 12       // FIR priority alternates between the two workgroups of a CU every 2^shift x 10 ns (0: off)
+#endif
+#ifndef FZ_START_DELAY
+#define FZ_START_DELAY 0        // x 10 ns: head start of the first workgroup of every CU (0: none)
+#endif
 #define FZ_MAXSLOTS 20          // chunk slots under one tile (LDS: two 4-wave workgroups per CU at K >= 448)
 
 // (the four arrays are separate __restrict__ kernel parameters, not members: only then can the compiler prove
@@ -191,6 +204,17 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     const int slot_b = slot_a + A.spw < A.nslots ? slot_a + A.spw : A.nslots;
     const int n_ev = slot_a < A.nslots ? slot_b - slot_a + 1 : 0;       // chunk IRs this wave evaluates per pass
 
+#if FZ_START_DELAY
+    // The two workgroups of a CU alternate between a latency-bound staging phase and a VALU-bound FIR phase.
+    // Started together they stage together (VALU idle) and then share the FIR phase; started half a pass apart,
+    // one stages while the other has the SIMDs to itself.  The second half of the grid (the blocks that join the
+    // first half's CUs under the observed dispatch order; speed only) waits FZ_START_DELAY x 10 ns before its
+    // first pass.
+    if (prio_flip) {
+        const unsigned long long t_go = __builtin_amdgcn_s_memrealtime() + FZ_START_DELAY;
+        while (__builtin_amdgcn_s_memrealtime() < t_go) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
 #ifdef BAS_STAMPS
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime();
@@ -212,7 +236,9 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             mo0 = (int)(xbase - cf * A.K);
         }
 
-        __builtin_amdgcn_s_setprio(3);                       // staging is latency bound: its few instructions go first
+#if FZ_STAGE_PRIO
+        __builtin_amdgcn_s_setprio(FZ_STAGE_PRIO);           // staging is latency bound: its few instructions go first
+#endif
         // ---- global -> registers: this wave's read plans (chunk IRs slot_a .. slot_b, both ears) and the x window
         f32x4 pv[2];
         {
@@ -274,6 +300,39 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             const f32x4 *pl = plw + half * (BAS_PLANS_WORDS / 4);
             const int tq = 4 * (lane & 31) + (lane < 32 ? 2 : 0);          // first of the two taps this lane stores
             f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tq;
+#if FZ_PIPE_FULL
+            // Two chunk IRs (2 x 16 table reads) are in flight at any time: a real loop, two IRs per iteration,
+            // without vector-memory work under a branch, so that the load counters carry across iterations.
+            // Indices past the wave's last IR re-request that IR; their results are not stored.
+            FzHalf pa, pb, qa, qb;
+            f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int last = n_ev > 0 ? n_ev - 1 : 0;        // (n_ev = 0: an idle wave reads stale but in-range plan words)
+            auto plan_of = [&](int i) { return pl + (i < last ? i : last) * PL4; };
+            auto store_slot = [&](int slot, const f32x4 &h0, const f32x4 &h1) {        // (IR slot, IR slot+1 - IR slot)
+                f32x2 h0a, h0b, da, db;
+                fz_pair_ears(h0, h0a, h0b);
+                fz_pair_ears(h1 - h0, da, db);
+                if (tq < Lseg) {
+                    dst[slot * (HD_SLOT / 4)] = f32x4{h0a.x, h0a.y, da.x, da.y};
+                    dst[slot * (HD_SLOT / 4) + 1] = f32x4{h0b.x, h0b.y, db.x, db.y};
+                }
+            };
+            fz_issue<0>(tab, plan_of(0), m4, L4, pa);
+            fz_issue<1>(tab, plan_of(0), m4, L4, pb);
+            for (int i = 0; i < n_ev; i += 2) {
+                fz_issue<0>(tab, plan_of(i + 1), m4, L4, qa);
+                fz_issue<1>(tab, plan_of(i + 1), m4, L4, qb);
+                f32x4 h = fz_finish<0>(plan_of(i), pa, f32x4{0.f, 0.f, 0.f, 0.f});
+                h = fz_finish<1>(plan_of(i), pb, h) * live;
+                if (i > 0) store_slot(i - 1, prev, h);
+                fz_issue<0>(tab, plan_of(i + 2), m4, L4, pa);
+                fz_issue<1>(tab, plan_of(i + 2), m4, L4, pb);
+                f32x4 h2 = fz_finish<0>(plan_of(i + 1), qa, f32x4{0.f, 0.f, 0.f, 0.f});
+                h2 = fz_finish<1>(plan_of(i + 1), qb, h2) * live;
+                if (i + 1 < n_ev) store_slot(i, h, h2);
+                prev = h2;
+            }
+#else
             FzHalf ha, hb;
             f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
             fz_issue<0>(tab, pl, m4, L4, ha);                // (n_ev = 0: reads stale plan words of an idle wave:
@@ -298,6 +357,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                 prev = h;
                 pl = pl_next;
             }
+#endif
         }
         FZ_STAMP(t4);
         __syncthreads();
@@ -311,11 +371,15 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         if (m_in < 0) { m_in += A.K; sl -= 1; }
         if (m_in >= A.K) { m_in -= A.K; sl += 1; }
         const f32x4 *xrow = xs4 + row_out;
+#if FZ_SLICE_SHIFT
         {   // fair time slicing between the two workgroups of a CU (see bas_render_hd_kernel)
-            const unsigned t = (unsigned)(__builtin_amdgcn_s_memrealtime() >> 12);
+            const unsigned t = (unsigned)(__builtin_amdgcn_s_memrealtime() >> FZ_SLICE_SHIFT);
             if ((t & 1u) ^ prio_flip) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
         }
+#elif FZ_STAGE_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         for (int rp = 0; rp <= halo; ++rp) {
             float al[1];
             if (A.s_pow2) {
@@ -397,8 +461,14 @@ static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
     // largest tile that still gives every workgroup slot of the chip a unit; scenes with few sources (one source
     // x 10 s is 54 tiles of 8192) take smaller tiles and with them more, narrower workgroups
     const int cand[3] = {4, 2, 1};
+#ifdef BAS_DIAG
+    const char *force_nw = getenv("BAS_FZ_NW");              // diagnostic build only: force the tile size
+#endif
     for (int ci = 0; ci < 3; ++ci) {
         const int nw = cand[ci];
+#ifdef BAS_DIAG
+        if (force_nw && atoi(force_nw) != nw) continue;
+#endif
         const int nslots = fz_slots(nw, K);
         const int maxev = nw == 4 ? 6 : 7;
         const int spw = (nslots + nw - 1) / nw;
@@ -412,7 +482,11 @@ static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
         const long slots = wg_per_cu * cus;
         const long n_tiles = (T_out + 2048L * nw - 1) / (2048L * nw);
         const long units = n_tiles * n_src;
+#ifdef BAS_DIAG
+        if (units < slots && nw > 1 && !force_nw) continue;
+#else
         if (units < slots && nw > 1) continue;               // not enough work for this tile: try a smaller one
+#endif
         p.nw = nw;
         p.tile = 2048 * nw;
         p.nslots = nslots;
