@@ -45,7 +45,7 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #define FZ_STAGE_PRIO 3         // wave priority while staging (0: leave it alone)
 #endif
 #ifndef FZ_SLICE_SHIFT
-#define FZ_SLICE_SHIFT 12       // FIR priority alternates between the two workgroups of a CU every 2^shift x 10 ns (0: off)
+#define FZ_SLICE_SHIFT 14       // FIR priority alternates between the two workgroups of a CU every 2^shift x 10 ns (0: off)
 #endif
 #ifndef FZ_START_DELAY
 #define FZ_START_DELAY 0        // x 10 ns: head start of the first workgroup of every CU (0: none)
