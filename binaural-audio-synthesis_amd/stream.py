@@ -14,30 +14,43 @@ cannot be applied to samples already handed out; the stream returns un-normalise
 and tracks the running peak (`peak`), so a caller can scale afterwards exactly as the
 reference would.  Long streams (BASELINE config 5: 1 h at 48 kHz, 1024 sources) never
 materialise more than one block of inputs, chunk IRs and outputs.
+
+All per-block state lives in buffers that are allocated once per block size, and one block
+is a fixed sequence of stream-ordered calls on them (angles -> parameters, read plans, fused
+FIR, carry copies, running peak).  From the second block of a size on that sequence is
+replayed as ONE hipGraph launch (graph=True, the default): a real-time caller feeding
+512-sample blocks pays one graph launch per block instead of a dozen Python-level launches.
 """
 from . import sphere
 from .apply_hrtf import as_device_table, render_params_device
 
 
 class StreamRenderer:
-    def __init__(self, tbl, n_src, chunksize, subchunksize):
+    def __init__(self, tbl, n_src, chunksize, subchunksize, graph=True, copy_out=True):
+        """graph: replay each block as one captured hipGraph (from the second block of a given size on).
+        copy_out: process() returns a fresh tensor (True) or a view of the renderer's output buffer that the
+        next process() call overwrites (False: no copy kernel; for callers that consume each block at once)."""
         import torch
         assert chunksize % subchunksize == 0, 'subchunksize does not divide chunksize evenly'
         self.tbl = as_device_table(tbl)
         self.n_src, self.K, self.S = int(n_src), int(chunksize), int(subchunksize)
         L = self.tbl.L
         self.halo = -(-(L - 1) // self.K) * self.K if L > 1 else 0
+        self.nh = self.halo // self.K                     # chunk boundaries carried with the halo
         dev = self.tbl.device
+        self.graph_enabled, self.copy_out = bool(graph), bool(copy_out)
         # input staging buffer [n_src, halo + capacity]: columns [0, halo) carry the previous inputs, a block
         # is rendered in place behind them (input_view() lets a producer write there directly: no copy)
         self._xbuf = torch.zeros((self.n_src, self.halo), dtype=torch.float32, device=dev)
-        self._idx_halo = None          # parameters at the halo's chunk boundaries, [n_src, halo/K, 4|3]
-        self._w_halo = None
-        self._idx_last = self._w_last = None
+        self._B = None                                    # block size the per-block buffers are laid out for
+        self._graph = None
+        self._halo_params = None                          # (idx [n_src, nh, 4], w [n_src, nh, 3]) across a re-layout
+        self._first = True
         self._peak_dev = torch.zeros((), dtype=torch.float32, device=dev)
         self.samples_in = 0
         self._finished = False
 
+    # ---- buffers ---------------------------------------------------------------------------------------
     def _reserve(self, B):
         import torch
         cap = self._xbuf.shape[1] - self.halo
@@ -45,6 +58,36 @@ class StreamRenderer:
             grown = torch.zeros((self.n_src, (self.halo + B + 3) // 4 * 4), dtype=torch.float32, device=self._xbuf.device)
             grown[:, :self.halo] = self._xbuf[:, :self.halo]
             self._xbuf = grown
+            self._graph = None                            # the captured pointers are gone
+
+    def _layout(self, B):
+        """Per-block buffers for blocks of B samples (kept until another size arrives)."""
+        import torch
+        from . import _hip
+        if self._B == B:
+            return
+        dev, n, nh = self.tbl.device, self.n_src, self.nh
+        nb = B // self.K + 1
+        if self._B is not None and not self._first:       # carry the halo's parameters into the new layout
+            self._halo_params = (self._idx_all[:, :nh].clone(), self._w_all[:, :nh].clone())
+        self._reserve(B)
+        self._B, self._nb, self._graph, self._blocks_in_layout = B, nb, None, 0
+        self._elev_in = torch.zeros((n, nb), dtype=torch.float64, device=dev)
+        self._azim_in = torch.zeros((n, nb), dtype=torch.float64, device=dev)
+        self._idx_blk = torch.zeros((n * nb, 4), dtype=torch.int32, device=dev)
+        self._w_blk = torch.zeros((n * nb, 3), dtype=torch.float64, device=dev)
+        self._idx_all = torch.zeros((n, nh + nb, 4), dtype=torch.int32, device=dev)      # boundaries t0-halo .. t0+B
+        self._w_all = torch.zeros((n, nh + nb, 3), dtype=torch.float64, device=dev)
+        if self._halo_params is not None:
+            self._idx_all[:, :nh], self._w_all[:, :nh] = self._halo_params
+            self._halo_params = None
+        self._y = torch.empty((2, self.halo + B + self.tbl.L - 1), dtype=torch.float32, device=dev)
+        lib = _hip.lib()
+        t_in = self.halo + B
+        wb = max(lib.bas_render_workspace_bytes(n, t_in, self.K, self.S, self.tbl.L),
+                 lib.bas_render_fused_workspace_bytes(n, t_in, self.K, self.S, self.tbl.L))
+        self._ws = torch.empty((wb,), dtype=torch.uint8, device=dev)
+        self._ws_plans = torch.empty((lib.bas_interp2d_workspace_bytes(n * (nh + nb)),), dtype=torch.uint8, device=dev)
 
     def input_view(self, B):
         """Device view [n_src, B] of the renderer's own input buffer.  A producer (decoder, H2D copy,
@@ -53,10 +96,42 @@ class StreamRenderer:
         self._reserve(B)
         return self._xbuf[:, self.halo:self.halo + B]
 
+    def trajectory_views(self, B):
+        """Device views (elev, azim), float64 [n_src, B/K + 1], of the renderer's own trajectory buffers for
+        blocks of B samples: a producer that fills them in place and passes them to process() saves two copies."""
+        self._layout(B)
+        return self._elev_in, self._azim_in
+
+    # ---- one block -------------------------------------------------------------------------------------
+    def _block_body(self):
+        """The stream-ordered work of one block on the per-block buffers (captured into the hipGraph)."""
+        import torch
+        B, nb, nh, halo = self._B, self._nb, self.nh, self.halo
+        # a3 on the device: angles -> (indices, weights), bit-identical to the host's vectorised form (tested)
+        sphere.interpolation_params_device(self._elev_in, self._azim_in, out=(self._idx_blk, self._w_blk))
+        self._idx_all[:, nh:] = self._idx_blk.view(self.n_src, nb, 4)
+        self._w_all[:, nh:] = self._w_blk.view(self.n_src, nb, 3)
+        if self._first:                                   # the halo holds silence, any valid IR will do
+            self._idx_all[:, :nh] = self._idx_all[:, nh:nh + 1]
+            self._w_all[:, :nh] = self._w_all[:, nh:nh + 1]
+        x = self._xbuf[:, :halo + B]
+        render_params_device(x, self.K, self.S, self.tbl, self._idx_all.view(-1, 4), self._w_all.view(-1, 3),
+                             normalize="none", out=self._y, ws=self._ws, ws_plans=self._ws_plans)
+        out = self._y[:, halo:halo + B]
+        self._peak_dev.copy_(torch.maximum(self._peak_dev, out.abs().max()))
+        # carry: last `halo` inputs and the parameters of their chunk boundaries (t0+B-halo .. t0+B-K)
+        if halo:
+            tail = x[:, B:B + halo]
+            self._xbuf[:, :halo] = tail.clone() if B < halo else tail            # ranges overlap only if B < halo
+            ia, wa = self._idx_all[:, nb - 1:nb - 1 + nh], self._w_all[:, nb - 1:nb - 1 + nh]
+            overlap = nb - 1 < nh
+            self._idx_all[:, :nh] = ia.clone() if overlap else ia
+            self._w_all[:, :nh] = wa.clone() if overlap else wa
+
     def process(self, block, elev, azim):
         """block: [n_src, B] (B a multiple of the chunk size); elev/azim: float64 [n_src, B/K + 1],
-        the trajectory at t = t0, t0+K, .., t0+B of this block (radians).  Returns the B stereo
-        samples this block completes as a device tensor (B, 2), un-normalised."""
+        the trajectory at t = t0, t0+K, .., t0+B of this block (radians; numpy arrays or device tensors).
+        Returns the B stereo samples this block completes as a device tensor (B, 2), un-normalised."""
         import torch
         assert not self._finished, "stream already finished"
         blk = torch.as_tensor(block)
@@ -64,41 +139,33 @@ class StreamRenderer:
         B = blk.shape[1]
         assert B % self.K == 0 and B > 0, 'block length must be a positive multiple of the chunk size'
         dev = self.tbl.device
-        # angles -> (indices, weights): on the device when the trajectory already lives there (long
-        # streams: no host work per block), else with the host's vectorised form; both are bit-identical
-        if isinstance(elev, torch.Tensor) and elev.is_cuda:
-            idx, w = sphere.interpolation_params_device(elev.to(torch.float64), torch.as_tensor(azim).to(dev, torch.float64))
-        else:
-            idx_h, w_h = sphere.interpolation_params_batch(elev, azim)
-            idx, w = torch.from_numpy(idx_h).to(dev), torch.from_numpy(w_h).to(dev)
-        nb = B // self.K + 1
-        if tuple(idx.shape[:2]) != (self.n_src, nb):
-            raise ValueError(f"elev/azim must have shape ({self.n_src}, {nb})")
-        nh = self.halo // self.K
-        if self._idx_halo is None:      # first block: the halo holds silence, any valid IR will do
-            self._idx_halo = idx[:, :1].repeat(1, nh, 1)
-            self._w_halo = w[:, :1].repeat(1, nh, 1)
-        idx_all = torch.cat([self._idx_halo, idx], dim=1)              # boundaries t0-halo .. t0+B
-        w_all = torch.cat([self._w_halo, w], dim=1)
-        self._reserve(B)
-        x = self._xbuf[:, :self.halo + B]
-        in_place = blk.is_cuda and blk.dtype == torch.float32 and blk.stride() == x.stride() and \
-            blk.data_ptr() == self._xbuf.data_ptr() + 4 * self.halo
+        self._layout(B)
+        nb = self._nb
+        for src, dst in ((elev, self._elev_in), (azim, self._azim_in)):
+            t = torch.as_tensor(src)
+            if tuple(t.shape) != (self.n_src, nb):
+                raise ValueError(f"elev/azim must have shape ({self.n_src}, {nb})")
+            if not (t.is_cuda and t.data_ptr() == dst.data_ptr() and t.dtype == torch.float64 and t.is_contiguous()):
+                dst.copy_(t)                              # (H2D for host arrays; float64 kept exactly)
+        x_dst = self._xbuf[:, self.halo:self.halo + B]
+        in_place = blk.is_cuda and blk.dtype == torch.float32 and blk.stride() == x_dst.stride() and \
+            blk.data_ptr() == x_dst.data_ptr()
         if not in_place:
-            x[:, self.halo:] = blk.to(device=dev, dtype=torch.float32)
-        y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_all.reshape(-1, 4).contiguous(),
-                                    w_all.reshape(-1, 3).contiguous(), normalize="none")
-        out = y[:, self.halo:self.halo + B]
-        # carry: last `halo` inputs and the parameters of their chunk boundaries (t0+B-halo .. t0+B-K)
-        if self.halo:
-            tail = x[:, B:B + self.halo]
-            self._xbuf[:, :self.halo] = tail.clone() if B < self.halo else tail      # ranges overlap only if B < halo
-            self._idx_halo = idx_all[:, nb - 1:nb - 1 + nh].clone()
-            self._w_halo = w_all[:, nb - 1:nb - 1 + nh].clone()
-        self._idx_last, self._w_last = idx[:, -1:].clone(), w[:, -1:].clone()   # boundary t0 + B
-        self._peak_dev = torch.maximum(self._peak_dev, out.abs().max()) if out.numel() else self._peak_dev
+            x_dst.copy_(blk)
+        if self._first or not self.graph_enabled or (self._graph is None and self._blocks_in_layout == 0):
+            self._block_body()                            # first block of a size: plain launches (also the warm-up)
+            self._first = False
+        else:
+            if self._graph is None:                       # second consecutive block of this size: capture once
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._block_body()
+                self._graph = g
+            self._graph.replay()
+        self._blocks_in_layout += 1
         self.samples_in += B
-        return out.t()
+        out = self._y[:, self.halo:self.halo + B].t()
+        return out.clone() if self.copy_out else out
 
     @property
     def peak(self):
@@ -111,12 +178,13 @@ class StreamRenderer:
         last process() call; the one after it only multiplies silence."""
         import torch
         assert not self._finished, "stream already finished"
-        if self._idx_last is None:
+        if self._first:
             raise RuntimeError("finish() before any block")
-        L = self.tbl.L
+        L, nh, nb = self.tbl.L, self.nh, self._nb
         dev = self.tbl.device
-        idx_all = torch.cat([self._idx_halo, self._idx_last, self._idx_last], dim=1)
-        w_all = torch.cat([self._w_halo, self._w_last, self._w_last], dim=1)
+        idx_last, w_last = self._idx_all[:, nh + nb - 1:nh + nb], self._w_all[:, nh + nb - 1:nh + nb]
+        idx_all = torch.cat([self._idx_all[:, :nh], idx_last, idx_last], dim=1)
+        w_all = torch.cat([self._w_all[:, :nh], w_last, w_last], dim=1)
         x = torch.cat([self._xbuf[:, :self.halo], torch.zeros((self.n_src, self.K), dtype=torch.float32, device=dev)], dim=1)
         y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_all.reshape(-1, 4).contiguous(),
                                     w_all.reshape(-1, 3).contiguous(), normalize="none")

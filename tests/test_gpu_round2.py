@@ -292,3 +292,46 @@ def test_device_table_cache_follows_rebinding(tables):
     pts = golden("interp2d.npz")
     one = bas.interpolate_2d(t, np.float64(pts["points"][7, 0]), np.float64(pts["points"][7, 1]))
     assert one.shape == (2, 100) and rel_err(one, pts["consistent_100"][7]) <= REL
+
+
+# ---------------------------------------------------------------------------
+# streaming: the hipGraph fast path
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("k,s,B", [(512, 32, 512), (512, 32, 2048), (128, 32, 128), (1024, 64, 1024)])
+def test_stream_graph_replay_equals_plain_launches(tables, k, s, B):
+    """From the second block of a size on StreamRenderer replays one captured hipGraph per block (a3, read plans,
+    fused FIR, carry copies, running peak).  Many equal blocks through the graph path == the same blocks through
+    plain launches (graph=False) == the whole-signal render; producers may write audio and trajectories straight
+    into the renderer's buffers (input_view / trajectory_views) and read the result in place (copy_out=False)."""
+    import torch
+    h = tables["consistent"].truncated(128)
+    d = _device_table(h)
+    n_src, n_blocks = 6, 9
+    n = B * n_blocks
+    sigs = torch.from_numpy(np.stack([bas.synth.integer_noise(300 + i, n, 0.1) for i in range(n_src)])).cuda()
+    t = np.arange(0, n + 1, k, dtype=np.float64)
+    elev = np.stack([bas.synth.trajectory("circle_askew", period_s=0.04 + 0.013 * i, phase=0.7 * i)(t)[0] for i in range(n_src)])
+    azim = np.stack([bas.synth.trajectory("circle_askew", period_s=0.04 + 0.013 * i, phase=0.7 * i)(t)[1] for i in range(n_src)])
+    whole = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none")
+    g = bas.StreamRenderer(d, n_src, k, s, graph=True, copy_out=False)
+    e = bas.StreamRenderer(d, n_src, k, s, graph=False)
+    outs_g, outs_e = [], []
+    for b in range(n_blocks):
+        c0, c1 = b * B // k, (b + 1) * B // k
+        xin = g.input_view(B)
+        ev, av = g.trajectory_views(B)
+        xin.copy_(sigs[:, b * B:(b + 1) * B])
+        ev.copy_(torch.from_numpy(elev[:, c0:c1 + 1].copy()))
+        av.copy_(torch.from_numpy(azim[:, c0:c1 + 1].copy()))
+        y = g.process(xin, ev, av)
+        assert y.data_ptr() == g._y.data_ptr() + 4 * g.halo                # a view of the renderer's own output
+        outs_g.append(y.clone())
+        outs_e.append(e.process(sigs[:, b * B:(b + 1) * B], elev[:, c0:c1 + 1], azim[:, c0:c1 + 1]))
+        assert torch.equal(outs_g[-1], outs_e[-1]), b
+    assert g._graph is not None and e._graph is None
+    outs_g.append(g.finish())
+    outs_e.append(e.finish())
+    got = torch.cat(outs_g, dim=0)
+    assert torch.equal(got, torch.cat(outs_e, dim=0))
+    assert got.shape == whole.shape and rel_err(got.cpu().numpy(), whole.cpu().numpy()) <= 1e-6
+    assert g.peak == e.peak and abs(g.peak - float(whole.abs().max())) <= 1e-6 * g.peak
