@@ -50,6 +50,9 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #ifndef FZ_START_DELAY
 #define FZ_START_DELAY 0        // x 10 ns: head start of the first workgroup of every CU (0: none)
 #endif
+#ifndef FZ_NT_LOADS
+#define FZ_NT_LOADS 0            // x window, plans and slabs are touched once: non-temporal, so that L2 keeps the table
+#endif
 #define FZ_MAXSLOTS 20          // chunk slots under one tile (LDS: two 4-wave workgroups per CU at K >= 448)
 
 // (the four arrays are separate __restrict__ kernel parameters, not members: only then can the compiler prove
@@ -183,8 +186,13 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         f32x4 *r4 = reinterpret_cast<f32x4 *>(dst + TILE);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
+#if FZ_NT_LOADS
+            __builtin_nontemporal_store(f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x}, l4 + i);
+            __builtin_nontemporal_store(f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y}, r4 + i);
+#else
             l4[i] = f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x};
             r4[i] = f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y};
+#endif
         }
 #pragma unroll
         for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
@@ -249,7 +257,11 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                 p = p < n_ev * PL4 ? p : 0;
                 const int i = (p * 3641) >> 16;              // p / 18 for p < 128
                 const int c = clampi(c0 + slot_a + i, 0, A.n_chunks);
+#if FZ_NT_LOADS
+                pv[r] = __builtin_nontemporal_load(pl_src + (long)c * PL4 + (p - i * PL4));
+#else
                 pv[r] = pl_src[(long)c * PL4 + (p - i * PL4)];
+#endif
             }
         }
         const float *xwin = x + (long)s * A.x_stride + xbase;
@@ -263,7 +275,11 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             int i = 4 * (tid + j * THREADS);
             i = i < x_lo ? x_lo : i;
             i = i > x_hi - 4 ? x_hi - 4 : i;                 // clamped into the row (T_in is a multiple of K >= 32)
+#if FZ_NT_LOADS
+            xv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xwin + i));   // streamed once: keep L2 for the table
+#else
             xv[j] = *reinterpret_cast<const f32x4 *>(xwin + i);
+#endif
         }
         FZ_STAMP_NW(t1);
         __syncthreads();                                     // previous pass has finished reading LDS
