@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbas_hip.so")
+# BAS_LIB_PATH: load another build of the same ABI instead (profiling tools use the diagnostic build this way)
+LIB_PATH = os.environ.get("BAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libbas_hip.so")
 
 _c_int, _c_long, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_void_p
 

@@ -70,6 +70,11 @@ struct FzArgs {
     int nslots;                 // chunk slots staged per pass (covers every window of this K and tile)
     int spw;                    // chunk slots per wave = ceil(nslots / NW)
     unsigned packed_bytes;
+    // direct output: every tile is finished by ONE workgroup (units_per_wg is a multiple of n_src, e.g. a single
+    // source), so the accumulators go straight to y and no slab / reduce pass exists
+    int direct;
+    int accumulate;
+    long T_out;
 };
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -144,7 +149,8 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     FzArgs A, const float *__restrict__ x,                   // [n_src] rows of T_in floats, stride A.x_stride
     float *__restrict__ slab,                                // [n_wg][parts_per_wg][2][tile]
     const float *__restrict__ packed,                        // table in phase-plane layout
-    const unsigned *__restrict__ plans) {                    // [n_src][n_chunks+1][2 ears][BAS_PLANS_WORDS]
+    const unsigned *__restrict__ plans,                      // [n_src][n_chunks+1][2 ears][BAS_PLANS_WORDS]
+    float *__restrict__ y, unsigned int *__restrict__ peak_bits) {   // direct output only: [2][T_out], max|y| bits
     constexpr int THREADS = 64 * NW;
     constexpr int TILE = 2048 * NW;
     constexpr int ROWS = TILE / 32 + HD_HALO;                // rows of 32 inputs in the x window
@@ -181,6 +187,43 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     const unsigned L4 = 4u * (unsigned)A.L;
 
     auto flush = [&](long tile) {
+        if (A.direct) {                                      // uniform
+            const long n0 = tile * TILE + 2048 * wv + 32 * lane;        // this lane's first output
+            float lmax = 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float *ye = y + (long)e * A.T_out + n0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    f32x4 v = e == 0 ? f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x}
+                                     : f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y};
+                    const long n = n0 + 4 * i;
+                    if (n + 3 < A.T_out) {
+                        f32x4_a4 *p = reinterpret_cast<f32x4_a4 *>(ye + 4 * i);   // (the right ear starts at 4 T_out bytes)
+                        if (A.accumulate) v += *p;
+                        *p = v;
+                        lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+                    } else {
+                        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (n + j < A.T_out) {
+                                const float r = A.accumulate ? vv[j] + ye[4 * i + j] : vv[j];
+                                ye[4 * i + j] = r;
+                                lmax = fmaxf(lmax, fabsf(r));
+                            }
+                        }
+                    }
+                }
+            }
+            if (peak_bits) {
+                for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+                if (lane == 0) atomicMax(peak_bits, __float_as_uint(lmax));
+            }
+#pragma unroll
+            for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+            return;
+        }
         float *dst = slab_wg + (tile - first_tile) * 2 * TILE + 2048 * wv + 32 * lane;
         f32x4 *l4 = reinterpret_cast<f32x4 *>(dst);
         f32x4 *r4 = reinterpret_cast<f32x4 *>(dst + TILE);
@@ -581,18 +624,21 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
     A.units_total = p.units_total; A.units_per_wg = p.units_per_wg; A.parts_per_wg = p.parts_per_wg;
     A.nslots = p.nslots; A.spw = p.spw;
     A.packed_bytes = (unsigned)table_bytes;
+    A.direct = p.units_per_wg % n_src == 0;
+    A.accumulate = accumulate;
+    A.T_out = T_out;
     float *slab = reinterpret_cast<float *>(ws);
-    typedef void (*fz_fn)(FzArgs, const float *, float *, const float *, const unsigned *);
+    typedef void (*fz_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
     const fz_fn fn = p.nw == 4 ? bas_render_fz_kernel<4> : (p.nw == 2 ? bas_render_fz_kernel<2> : bas_render_fz_kernel<1>);
     hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     hipEvent_t eb = reinterpret_cast<hipEvent_t>(ev_begin), ee = reinterpret_cast<hipEvent_t>(ev_end);
     if (eb) (void)hipEventRecord(eb, st);
     hipLaunchKernelGGL(fn, dim3(p.n_wg), dim3(64 * p.nw), p.lds_bytes, st, A, x, slab, packed,
-                       reinterpret_cast<const unsigned *>(plans));
+                       reinterpret_cast<const unsigned *>(plans), y, peak_bits);
     if (ee) (void)hipEventRecord(ee, st);
     int rc = bas_check_launch("bas_render_mix_fused_f32(fz)");
-    if (rc) return rc;
+    if (rc || A.direct) return rc;                           // direct output: y and the peak are complete
     return bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
                                   peak_bits, st, "bas_render_mix_fused_f32(reduce)");
 }
