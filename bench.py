@@ -57,6 +57,9 @@ def parse():
                     help="strong (default): BASELINE config 4 read literally, ONE --sources-source scene sharded "
                          "over the GPUs; weak: every GPU renders --sources sources")
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the second (weak) measurement")
+    ap.add_argument("--settle-ms", type=float, default=400.0,
+                    help="untimed steps for this many milliseconds BEFORE the --warmup steps: a cold MI355X needs ~40 ms "
+                         "of load before its clock governor settles (profiles/r02_warmup_series.txt); 0 = off")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--chunk", type=int, default=512)
     ap.add_argument("--subchunk", type=int, default=32)
@@ -264,7 +267,11 @@ def self_launch(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in r.stdout.splitlines():                       # the launcher may add lines of its own: relay the JSON only
+        if line.lstrip().startswith("{"):
+            print(line, flush=True)
+    return r.returncode
 
 
 class Scene:
@@ -402,6 +409,18 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    if args.settle_ms > 0:                                  # untimed: let the clock governor reach its steady state
+        t_end = time.perf_counter() + args.settle_ms / 1e3
+        while True:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(dev)
+            go_on = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], dtype=torch.float64,
+                                 device="cpu" if backend != "nccl" else dev)
+            if world > 1:                                    # every rank must leave the loop at the same step count
+                dist.all_reduce(go_on, op=dist.ReduceOp.MIN)
+            if float(go_on.item()) == 0.0:
+                break
     for _ in range(args.warmup):
         step()
     fence()
@@ -503,6 +522,7 @@ def main():
             "value": value, "unit": "stereo samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "settle": f"{args.settle_ms:g} ms of untimed steps before the {args.warmup} warm-up steps (clock governor)",
             "config": {"workload": f"BASELINE config 4: {sc.total_src} moving sources x {args.seconds:g} s @ {FS} Hz mono "
                                    f"-> 1 stereo mix; chunk {k}, subchunk {s}, {l}-tap HRIRs (U=8, 187 directions), "
                                    f"spiral/askew-circle trajectories given as (elev, azim) per chunk boundary on the "

@@ -50,3 +50,32 @@ def test_table_structure_and_mat_layout(tmp_path):
     assert int(rec["upsampling"][0][0]) == 8
     assert rec["irs_right"][:, :16 * 8].shape == (n_dir, 128)
     assert np.array_equal(rec["diffs_left"], t["diffs_left"])
+
+
+def test_batched_rows_equal_the_per_pair_function():
+    """delaydifferences_from (one FFT batch per row of the pair matrix) against delaydifference pair by pair, and the
+    reference's preconditions (upsample_irs.m:90-98) as assertions."""
+    rng = np.random.default_rng(5)
+    n_dir, n_taps = 7, 96
+    h = np.stack([_pulse(n_taps, 30 + rng.uniform(-6, 6), width=2.0 + rng.uniform(0, 2)) for _ in range(n_dir)])
+    h += 0.01 * rng.standard_normal(h.shape)
+    for i in range(n_dir):
+        got = up.delaydifferences_from(h, i, 8)
+        want = np.array([up.delaydifference(h[i], h[j], 8) for j in range(i + 1, n_dir)])
+        assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=1e-9)
+    with pytest.raises(AssertionError):                      # a flat correlation has no strict peak: a == 0 (:97)
+        up.delaydifferences_from(np.zeros((2, 16)), 0, 8)
+
+
+def test_full_size_table_builds_quickly():
+    """187 directions x 512 taps, U = 8 (the real table's shape) on synthetic pulses: structure only."""
+    import time
+    rng = np.random.default_rng(9)
+    pos = 40 + rng.uniform(-10, 10, size=(2, 187))
+    hl = np.stack([_pulse(512, p) for p in pos[0]])
+    hr = np.stack([_pulse(512, p) for p in pos[1]])
+    t0 = time.perf_counter()
+    t = up.upsample_irs(hl, hr, 8)
+    assert time.perf_counter() - t0 < 240
+    assert t["irs_left"].shape == (187, 4096) and t["diffs_right"].shape == (187, 187)
+    assert np.allclose(t["diffs_left"], pos[0][None, :] - pos[0][:, None], atol=5e-3)

@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Copies the measurements tools/collect_profiles.sh left under gpurun_out/r02p/ into profiles/ (tracked):
+summaries as they are, counter CSVs reduced to this library's kernels, and profiles/fir_hbm_traffic.json
+recomputed from the FETCH_SIZE / WRITE_SIZE passes (what bench.py replays as roofline.traffic)."""
+import collections, csv, io, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r02p")
+DST = os.path.join(ROOT, "profiles")
+TAG = "r02_"
+
+
+def copy(rel, name):
+    p = os.path.join(SRC, rel)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copyfile(p, os.path.join(DST, TAG + name))
+        return True
+    print("missing:", rel)
+    return False
+
+
+def filter_counters(rel, name):
+    p = os.path.join(SRC, rel)
+    if not os.path.exists(p):
+        print("missing:", rel)
+        return {}
+    rows = list(csv.DictReader(open(p)))
+    keep = [r for r in rows if "bas_" in r["Kernel_Name"]]
+    with open(os.path.join(DST, TAG + name), "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(keep)
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in keep:
+        per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+
+for rel, name in [("bench_default.json", "bench.json"), ("bench_300.json", "bench_300steps.json"),
+                  ("bench_profiled.json", "bench_profiled.json"), ("prof/bench_kernel_stats.csv", "kernel_stats.csv"),
+                  ("bench_unfused.json", "bench_unfused.json"), ("prof_unfused/bench_kernel_stats.csv", "kernel_stats_unfused.csv"),
+                  ("single_source.json", "single_source.json"), ("prof_single/bench_kernel_stats.csv", "kernel_stats_single_source.csv"),
+                  ("single_source_tile8192.json", "single_source_tile8192.json"), ("single_source_latency.txt", "single_source_latency.txt"),
+                  ("stream_1024src_48k.json", "stream_1024src_48k.json"), ("stream_1024src_48k_regen.json", "stream_1024src_48k_regen.json"),
+                  ("stream_host_time.txt", "stream_host_time.txt"), ("ubench_fir_pattern.txt", "ubench_fir_pattern.txt"),
+                  ("ubench_fma_forms.txt", "ubench_fma_forms.txt"), ("ubench_fir_steps.txt", "ubench_fir_steps.txt"),
+                  ("stamps_fz_256.txt", "stamps_fz_256sources.txt"), ("bench_2ranks_one_device.json", "bench_2ranks_one_device.json")]:
+    copy(rel, name)
+
+fetch = filter_counters("pmc_FETCH_SIZE/pmc_counter_collection.csv", "pmc_FETCH_SIZE.csv")
+write = filter_counters("pmc_WRITE_SIZE/pmc_counter_collection.csv", "pmc_WRITE_SIZE.csv")
+filter_counters("pmc_SQ/pmc_counter_collection.csv", "pmc_SQ.csv")
+filter_counters("pmc_SQ2/pmc_counter_collection.csv", "pmc_SQ2.csv")
+for sq in ("pmc_SQ", "pmc_SQ2"):
+    p = os.path.join(SRC, sq, "pmc_counter_collection.csv")
+    if os.path.exists(p):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sq_summary.py"), p, "bas_render_fz"],
+                             capture_output=True, text=True).stdout
+        open(os.path.join(DST, TAG + sq + "_fz_kernel_summary.txt"), "w").write(out)
+
+fz = [k for k in fetch if "bas_render_fz_kernel" in k]
+if fz and any("bas_render_fz_kernel" in k for k in write):
+    kf = fz[0]
+    kw = [k for k in write if "bas_render_fz_kernel" in k][0]
+    f_kb = sum(fetch[kf]["FETCH_SIZE"]) / len(fetch[kf]["FETCH_SIZE"])
+    w_kb = sum(write[kw]["WRITE_SIZE"]) / len(write[kw]["WRITE_SIZE"])
+    rec = {"workload": "256x441000@K512S32L128", "fused": True, "kernel": "bas_render_fz_kernel<4>",
+           "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/r02_pmc_FETCH_SIZE.csv, "
+                     "r02_pmc_WRITE_SIZE.csv), mean over the dispatches of python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
+           "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
+           "correction": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced "
+                         "streaming read (the x window, 459 MB, is read 16 B/lane) -> doubled; WRITE_SIZE is exact for 16-B/lane "
+                         "stores.  The table gathers (unaligned 16-B buffer loads, mostly L2 hits) and the plan reads are "
+                         "uncalibrated: doubling them too makes this an upper bound.",
+           "bytes_per_launch": int(2 * f_kb * 1024 + w_kb * 1024),
+           "lower_bound_bytes_if_only_x_is_doubled": int((f_kb * 1024 + 229.5e6) + w_kb * 1024)}
+    json.dump(rec, open(os.path.join(DST, "fir_hbm_traffic.json"), "w"), indent=1)
+    print("traffic MB:", rec["bytes_per_launch"] / 1e6)
+print(sorted(os.listdir(DST)))
