@@ -35,6 +35,7 @@ python3 tools/stream_host_time.py 256 32768 2>/dev/null >> $O/stream_host_time.t
 ./tools/ubench_fir_pattern 1.0 > $O/ubench_fir_pattern.txt 2>&1
 ./tools/ubench_fma_forms 0.5 > $O/ubench_fma_forms.txt 2>&1
 ./tools/ubench_fir_steps > $O/ubench_fir_steps.txt 2>&1
+python3 tools/warmup_series.py 2>/dev/null > $O/warmup_series.txt
 # 8. phase stamps of the fused kernel (diagnostic build)
 python3 tools/stamps_fz.py 256 2>/dev/null > $O/stamps_fz_256.txt
 # 9. two ranks on one device (rehearsal of the multi-rank bench path)

@@ -43,7 +43,7 @@ for rel, name in [("bench_default.json", "bench.json"), ("bench_300.json", "benc
                   ("stream_1024src_48k.json", "stream_1024src_48k.json"), ("stream_1024src_48k_regen.json", "stream_1024src_48k_regen.json"),
                   ("stream_host_time.txt", "stream_host_time.txt"), ("ubench_fir_pattern.txt", "ubench_fir_pattern.txt"),
                   ("ubench_fma_forms.txt", "ubench_fma_forms.txt"), ("ubench_fir_steps.txt", "ubench_fir_steps.txt"),
-                  ("stamps_fz_256.txt", "stamps_fz_256sources.txt"), ("bench_2ranks_one_device.json", "bench_2ranks_one_device.json")]:
+                  ("stamps_fz_256.txt", "stamps_fz_256sources.txt"), ("warmup_series.txt", "warmup_series.txt"), ("bench_2ranks_one_device.json", "bench_2ranks_one_device.json")]:
     copy(rel, name)
 
 fetch = filter_counters("pmc_FETCH_SIZE/pmc_counter_collection.csv", "pmc_FETCH_SIZE.csv")
