@@ -18,8 +18,8 @@
 //     LDS image, one barrier less per pass.
 //   * (tile, source, tap segment) advance by scalar counters and the window's chunk arithmetic is redone only
 //     when the tile changes: no 64-bit divisions per pass; the per-lane chunk slot comes from a float estimate.
-//   * NW = 4, 2 or 1 waves per workgroup (tile 8192 / 4096 / 2048): scenes with few sources (BASELINE configs
-//     2 and 3: ONE source) get four times the workgroups out of the same signal.
+//   * NW = 4 or 1 waves per workgroup (tile 8192 / 2048): scenes with few sources (BASELINE configs 2 and 3:
+//     ONE source) get four times the workgroups out of the same signal.
 // No MFMA: this is a 1-D FIR (BASELINE.json north_star).
 #include "bas_internal.h"
 #include "bas_plan.h"
@@ -519,11 +519,11 @@ static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
     const int cus = bas_device_cus();
     // largest tile that still gives every workgroup slot of the chip a unit; scenes with few sources (one source
     // x 10 s is 54 tiles of 8192) take smaller tiles and with them more, narrower workgroups
-    const int cand[3] = {4, 2, 1};
+    const int cand[2] = {4, 1};                              // (a tile of 4096 never wins: same number of busy waves as 2048)
 #ifdef BAS_DIAG
     const char *force_nw = getenv("BAS_FZ_NW");              // diagnostic build only: force the tile size
 #endif
-    for (int ci = 0; ci < 3; ++ci) {
+    for (int ci = 0; ci < 2; ++ci) {
         const int nw = cand[ci];
 #ifdef BAS_DIAG
         if (force_nw && atoi(force_nw) != nw) continue;
@@ -629,7 +629,7 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
     A.T_out = T_out;
     float *slab = reinterpret_cast<float *>(ws);
     typedef void (*fz_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
-    const fz_fn fn = p.nw == 4 ? bas_render_fz_kernel<4> : (p.nw == 2 ? bas_render_fz_kernel<2> : bas_render_fz_kernel<1>);
+    const fz_fn fn = p.nw == 4 ? bas_render_fz_kernel<4> : bas_render_fz_kernel<1>;
     hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     hipEvent_t eb = reinterpret_cast<hipEvent_t>(ev_begin), ee = reinterpret_cast<hipEvent_t>(ev_end);

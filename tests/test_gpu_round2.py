@@ -335,3 +335,62 @@ def test_stream_graph_replay_equals_plain_launches(tables, k, s, B):
     assert torch.equal(got, torch.cat(outs_e, dim=0))
     assert got.shape == whole.shape and rel_err(got.cpu().numpy(), whole.cpu().numpy()) <= 1e-6
     assert g.peak == e.peak and abs(g.peak - float(whole.abs().max())) <= 1e-6 * g.peak
+
+
+# ---------------------------------------------------------------------------
+# fused entry point: accumulate, direct output, long IRs
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n_src,n,l", [(1, 30000, 128), (1, 9000, 300), (6, 20000, 128), (40, 150000, 100)])
+def test_fused_accumulate_and_direct_output(tables, n_src, n, l):
+    """bas_render_mix_fused_f32 called directly: rendering the sources in two calls, the second with accumulate = 1,
+    equals one call (and the oracle), and the reported peak is max|y| of the sum.  One source takes the direct-output
+    form (no slabs; also with three tap segments at L = 300), several sources the slab + reduce form (40 x 150 000:
+    tiles of 8192)."""
+    import torch
+    from binaural_audio_synthesis_amd import _hip
+    h = tables["consistent"].truncated(l)
+    d = _device_table(h)
+    k, s = 512, 32
+    sigs = np.stack([bas.synth.integer_noise(1200 + i, n, 0.3 / n_src) for i in range(n_src)])
+    in_length = -(-n // k) * k
+    t = np.arange(0, in_length + 1, k, dtype=np.float64)
+    elev = np.stack([bas.synth.trajectory("spiral", length_s=n / 44100, turns=1.0 + i % 5, phase=0.4 * i)(t)[0] for i in range(n_src)])
+    azim = np.stack([bas.synth.trajectory("spiral", length_s=n / 44100, turns=1.0 + i % 5, phase=0.4 * i)(t)[1] for i in range(n_src)])
+    lib = _hip.lib()
+    x = torch.zeros((n_src, in_length), dtype=torch.float32, device="cuda")
+    x[:, :n] = torch.from_numpy(sigs).cuda()
+    idx, w = bas.sphere.interpolation_params_device(torch.from_numpy(elev).cuda(), torch.from_numpy(azim).cuda())
+    idx, w = idx.reshape(-1, 4), w.reshape(-1, 3)
+    n_q = in_length // k + 1
+    t_out = in_length + l - 1
+    stream = _hip.current_stream(x.device)
+
+    def fused(x_part, idx_part, w_part, y, accumulate):
+        ns = x_part.shape[0]
+        assert lib.bas_render_fused_supported(ns, in_length, k, s, l) == 1
+        plans = torch.empty((lib.bas_interp2d_workspace_bytes(idx_part.shape[0]),), dtype=torch.uint8, device="cuda")
+        ws = torch.empty((lib.bas_render_fused_workspace_bytes(ns, in_length, k, s, l),), dtype=torch.uint8, device="cuda")
+        peak = torch.zeros(1, dtype=torch.float32, device="cuda")
+        _hip.call("bas_interp2d_plan_f32", _hip.ptr(d.diffs), _hip.ptr(idx_part), _hip.ptr(w_part), idx_part.shape[0], d.ndir, l,
+                  d.upsampling, _hip.ptr(plans), plans.numel(), stream)
+        _hip.call("bas_render_mix_fused_f32", _hip.ptr(x_part), x_part.stride(0), _hip.ptr(d.packed), _hip.ptr(plans), ns, in_length,
+                  k, s, l, d.upsampling, d.ndir, _hip.ptr(y), accumulate, _hip.ptr(peak), _hip.ptr(ws), ws.numel(), stream, None, None)
+        return float(peak)
+
+    y_one = torch.full((2, t_out), 7.0, dtype=torch.float32, device="cuda")            # must be overwritten
+    p_one = fused(x, idx.contiguous(), w.contiguous(), y_one, 0)
+    irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(n_q)]) for i in range(n_src)]
+    want = orc.render_mix(sigs, k, s, irs, normalize=False)
+    assert rel_err(y_one.t().cpu().numpy(), want) <= REL
+    assert abs(p_one - float(y_one.abs().max())) <= 1e-6 * p_one
+    # the same scene in two calls: first part overwrites, second accumulates (a single source: itself twice)
+    cut = max(n_src // 2, 1)
+    y_two = torch.full((2, t_out), -3.0, dtype=torch.float32, device="cuda")
+    fused(x[:cut].contiguous(), idx[:cut * n_q].contiguous(), w[:cut * n_q].contiguous(), y_two, 0)
+    rest = slice(cut, n_src) if n_src > 1 else slice(0, 1)
+    r0, r1 = rest.start * n_q, rest.stop * n_q
+    p_two = fused(x[rest].contiguous(), idx[r0:r1].contiguous(), w[r0:r1].contiguous(), y_two, 1)
+    expect = y_one if n_src > 1 else 2 * y_one
+    scale = float(expect.abs().max())
+    assert float((y_two - expect).abs().max()) <= 2e-6 * scale
+    assert abs(p_two - float(y_two.abs().max())) <= 1e-6 * scale
