@@ -308,7 +308,8 @@ class Scene:
         self.idx = torch.empty((n_src * n_q, 4), dtype=torch.int32, device=dev)
         self.w = torch.empty((n_src * n_q, 3), dtype=torch.float64, device=dev)
         lib = _hip.lib()
-        self.ws = torch.empty((lib.bas_render_workspace_bytes(n_src, in_length, k, s, l),), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty((max(lib.bas_render_workspace_bytes(n_src, in_length, k, s, l),
+                                   lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l)),), dtype=torch.uint8, device=dev)
         self.ws_i = torch.empty((lib.bas_interp2d_workspace_bytes(n_src * n_q),), dtype=torch.uint8, device=dev)
         self.y = torch.empty((2, t_out), dtype=torch.float32, device=dev)
         self.parts = torch.empty((world, 2, t_out), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
@@ -317,16 +318,15 @@ class Scene:
         env_fused = os.environ.get("BAS_BENCH_FUSED")            # ablation: "0" forces interp2d + render_mix
         self.fused = None if env_fused is None else env_fused == "1"
         self.fused_used = bool(lib.bas_render_fused_supported(n_src, in_length, k, s, l)) and self.fused is not False
-        self.kernel = lib.bas_render_kernel_name(n_src, in_length, k, s, l).decode()
+        self.kernel = "bas_render_fz_kernel" if self.fused_used else lib.bas_render_kernel_name(n_src, in_length, k, s, l).decode()
         self.host_u = host_u
 
     def render_into(self, y_buf, events):
         """a3 -> plans -> (chunk IRs +) FIR + mix + peak, all on the current stream."""
         bas, a = self.bas, self.args
-        bas.sphere.interpolation_params_device(self.elev, self.azim, out=(self.idx, self.w))
-        return bas.apply_hrtf.render_params_device(self.x, a.chunk, a.subchunk, self.tbl, self.idx, self.w,
+        return bas.apply_hrtf.render_angles_device(self.x, a.chunk, a.subchunk, self.tbl, self.elev, self.azim,
                                                    normalize="none", out=y_buf, events=events, ws=self.ws,
-                                                   ws_plans=self.ws_i, fused=self.fused)[1]
+                                                   ws_plans=self.ws_i, fused=self.fused, params=(self.idx, self.w))[1]
 
 
 def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_events):
@@ -539,7 +539,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": algo_bytes / fir_s / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / fir_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
-                         "kernel": sc.kernel + (" (fused: chunk IRs evaluated while staging)" if sc.fused_used else ""),
+                         "kernel": sc.kernel + (" (chunk IRs evaluated while staging)" if sc.fused_used else ""),
                          "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes},
             "valu": {"achieved": algo_flops / fir_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": algo_flops / fir_s / 1e12 / FP32_VALU_PEAK_TF,

@@ -296,6 +296,24 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     return y, peak
 
 
+def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize="mix", out=None, events=None,
+                         ws=None, ws_plans=None, fused=None, params=None):
+    """The whole device side of make_signal_move_2d for trajectories that live on the GPU: x [n_src, T_in] device
+    float32 (T_in % K == 0), elev / azim float64 device tensors [n_src, T_in/K + 1] (radians at t = 0, K, .., T_in).
+    bas_traj_params_f64 (a3 + the elevation bracket), then render_params_device (read plans + fused FIR where the
+    sizes allow it).  `params` = optional (idx [n, 4] int32, w [n, 3] float64) buffers to write the parameters
+    into (no allocation per call).  Returns (y [2, T_out], peak).
+    (A single kernel for a3 + read plans was tried: every (query, ear) thread then redoes the angle arithmetic and
+    the merged kernel took 53 us against 9 + 25 us for the two.)"""
+    tbl = as_device_table(tbl)
+    n_src, t_in = x.shape
+    if elev.numel() != n_src * (t_in // chunksize + 1) or azim.numel() != elev.numel():
+        raise ValueError("elev/azim must hold one angle per source and chunk boundary")
+    idx, w = sphere.interpolation_params_device(elev, azim, out=params)
+    return render_params_device(x, chunksize, subchunksize, tbl, idx.reshape(-1, 4), w.reshape(-1, 3), normalize,
+                                out=out, events=events, ws=ws, ws_plans=ws_plans, fused=fused)
+
+
 def _params_to_device(tbl, idx, w):
     import torch
     idx_t = torch.as_tensor(idx, dtype=torch.int32).reshape(-1, 4).contiguous().to(tbl.device)

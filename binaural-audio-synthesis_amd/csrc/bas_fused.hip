@@ -173,6 +173,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     if (unit1 > A.units_total) unit1 = A.units_total;
     const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
     const long n_pass = (unit1 - unit0) * nseg;
+    if (!A.direct && peak_bits && blockIdx.x == 0 && tid == 0) *peak_bits = 0u;   // the reduce kernel maxes into it later
     if (n_pass <= 0) return;
 
     f32x2 acc[32];
@@ -588,12 +589,12 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
     hipStream_t st = bas_stream(stream);
     const long T_out = T_in + L - 1;
     unsigned int *peak_bits = reinterpret_cast<unsigned int *>(peak);
-    if (peak) {
-        hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);
-        if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
-    }
     const bool live = n_src > 0 && T_in > 0;
     if (!live) {                                             // nothing to render: y = 0 (or untouched), peak = max|y|
+        if (peak) {
+            hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);
+            if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+        }
         if (!accumulate) {
             hipError_t e = hipMemsetAsync(y, 0, (size_t)2 * T_out * sizeof(float), st);
             if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
@@ -625,6 +626,11 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
     A.nslots = p.nslots; A.spw = p.spw;
     A.packed_bytes = (unsigned)table_bytes;
     A.direct = p.units_per_wg % n_src == 0;
+    if (peak && A.direct) {                                  // direct output: workgroups max into the peak as they finish.
+        hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);          // (slab form: the FIR kernel clears it, the
+        if (e != hipSuccess)                                                //  reduce kernel behind it takes the max)
+            return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+    }
     A.accumulate = accumulate;
     A.T_out = T_out;
     float *slab = reinterpret_cast<float *>(ws);

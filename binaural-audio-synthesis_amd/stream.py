@@ -22,7 +22,7 @@ replayed as ONE hipGraph launch (graph=True, the default): a real-time caller fe
 512-sample blocks pays one graph launch per block instead of a dozen Python-level launches.
 """
 from . import sphere
-from .apply_hrtf import as_device_table, render_params_device
+from .apply_hrtf import as_device_table, render_angles_device
 
 
 class StreamRenderer:
@@ -44,7 +44,7 @@ class StreamRenderer:
         self._xbuf = torch.zeros((self.n_src, self.halo), dtype=torch.float32, device=dev)
         self._B = None                                    # block size the per-block buffers are laid out for
         self._graph = None
-        self._halo_params = None                          # (idx [n_src, nh, 4], w [n_src, nh, 3]) across a re-layout
+        self._halo_params = None                          # (elev, azim) [n_src, nh] of the halo's boundaries across a re-layout
         self._first = True
         self._peak_dev = torch.zeros((), dtype=torch.float32, device=dev)
         self.samples_in = 0
@@ -68,19 +68,18 @@ class StreamRenderer:
             return
         dev, n, nh = self.tbl.device, self.n_src, self.nh
         nb = B // self.K + 1
-        if self._B is not None and not self._first:       # carry the halo's parameters into the new layout
-            self._halo_params = (self._idx_all[:, :nh].clone(), self._w_all[:, :nh].clone())
+        if self._B is not None and not self._first:       # carry the halo's angles into the new layout
+            self._halo_params = (self._elev_all[:, :nh].clone(), self._azim_all[:, :nh].clone())
         self._reserve(B)
         self._B, self._nb, self._graph, self._blocks_in_layout = B, nb, None, 0
-        self._elev_in = torch.zeros((n, nb), dtype=torch.float64, device=dev)
-        self._azim_in = torch.zeros((n, nb), dtype=torch.float64, device=dev)
-        self._idx_blk = torch.zeros((n * nb, 4), dtype=torch.int32, device=dev)
-        self._w_blk = torch.zeros((n * nb, 3), dtype=torch.float64, device=dev)
-        self._idx_all = torch.zeros((n, nh + nb, 4), dtype=torch.int32, device=dev)      # boundaries t0-halo .. t0+B
-        self._w_all = torch.zeros((n, nh + nb, 3), dtype=torch.float64, device=dev)
+        # trajectory at the chunk boundaries t0-halo .. t0+B: [halo part carried | this block's part]
+        self._elev_all = torch.zeros((n, nh + nb), dtype=torch.float64, device=dev)
+        self._azim_all = torch.zeros((n, nh + nb), dtype=torch.float64, device=dev)
         if self._halo_params is not None:
-            self._idx_all[:, :nh], self._w_all[:, :nh] = self._halo_params
+            self._elev_all[:, :nh], self._azim_all[:, :nh] = self._halo_params
             self._halo_params = None
+        self._idx = torch.empty((n * (nh + nb), 4), dtype=torch.int32, device=dev)
+        self._w = torch.empty((n * (nh + nb), 3), dtype=torch.float64, device=dev)
         self._y = torch.empty((2, self.halo + B + self.tbl.L - 1), dtype=torch.float32, device=dev)
         lib = _hip.lib()
         t_in = self.halo + B
@@ -98,35 +97,33 @@ class StreamRenderer:
 
     def trajectory_views(self, B):
         """Device views (elev, azim), float64 [n_src, B/K + 1], of the renderer's own trajectory buffers for
-        blocks of B samples: a producer that fills them in place and passes them to process() saves two copies."""
+        blocks of B samples (strided: they sit behind the carried halo boundaries): a producer that fills them in
+        place and passes them to process() saves two copies."""
         self._layout(B)
-        return self._elev_in, self._azim_in
+        return self._elev_all[:, self.nh:], self._azim_all[:, self.nh:]
 
     # ---- one block -------------------------------------------------------------------------------------
     def _block_body(self):
         """The stream-ordered work of one block on the per-block buffers (captured into the hipGraph)."""
         import torch
         B, nb, nh, halo = self._B, self._nb, self.nh, self.halo
-        # a3 on the device: angles -> (indices, weights), bit-identical to the host's vectorised form (tested)
-        sphere.interpolation_params_device(self._elev_in, self._azim_in, out=(self._idx_blk, self._w_blk))
-        self._idx_all[:, nh:] = self._idx_blk.view(self.n_src, nb, 4)
-        self._w_all[:, nh:] = self._w_blk.view(self.n_src, nb, 3)
-        if self._first:                                   # the halo holds silence, any valid IR will do
-            self._idx_all[:, :nh] = self._idx_all[:, nh:nh + 1]
-            self._w_all[:, :nh] = self._w_all[:, nh:nh + 1]
+        if self._first:                                   # the halo holds silence, any valid direction will do
+            self._elev_all[:, :nh] = self._elev_all[:, nh:nh + 1]
+            self._azim_all[:, :nh] = self._azim_all[:, nh:nh + 1]
         x = self._xbuf[:, :halo + B]
-        render_params_device(x, self.K, self.S, self.tbl, self._idx_all.view(-1, 4), self._w_all.view(-1, 3),
-                             normalize="none", out=self._y, ws=self._ws, ws_plans=self._ws_plans)
+        # a3, read plans, chunk IRs + FIR + mix (or the stored-IR path for other sizes)
+        render_angles_device(x, self.K, self.S, self.tbl, self._elev_all, self._azim_all, normalize="none",
+                             out=self._y, ws=self._ws, ws_plans=self._ws_plans, params=(self._idx, self._w))
         out = self._y[:, halo:halo + B]
         self._peak_dev.copy_(torch.maximum(self._peak_dev, out.abs().max()))
-        # carry: last `halo` inputs and the parameters of their chunk boundaries (t0+B-halo .. t0+B-K)
+        # carry: last `halo` inputs and the angles at their chunk boundaries (t0+B-halo .. t0+B-K)
         if halo:
             tail = x[:, B:B + halo]
             self._xbuf[:, :halo] = tail.clone() if B < halo else tail            # ranges overlap only if B < halo
-            ia, wa = self._idx_all[:, nb - 1:nb - 1 + nh], self._w_all[:, nb - 1:nb - 1 + nh]
+            ea, aa = self._elev_all[:, nb - 1:nb - 1 + nh], self._azim_all[:, nb - 1:nb - 1 + nh]
             overlap = nb - 1 < nh
-            self._idx_all[:, :nh] = ia.clone() if overlap else ia
-            self._w_all[:, :nh] = wa.clone() if overlap else wa
+            self._elev_all[:, :nh] = ea.clone() if overlap else ea
+            self._azim_all[:, :nh] = aa.clone() if overlap else aa
 
     def process(self, block, elev, azim):
         """block: [n_src, B] (B a multiple of the chunk size); elev/azim: float64 [n_src, B/K + 1],
@@ -141,11 +138,11 @@ class StreamRenderer:
         dev = self.tbl.device
         self._layout(B)
         nb = self._nb
-        for src, dst in ((elev, self._elev_in), (azim, self._azim_in)):
+        for src, dst in ((elev, self._elev_all[:, self.nh:]), (azim, self._azim_all[:, self.nh:])):
             t = torch.as_tensor(src)
             if tuple(t.shape) != (self.n_src, nb):
                 raise ValueError(f"elev/azim must have shape ({self.n_src}, {nb})")
-            if not (t.is_cuda and t.data_ptr() == dst.data_ptr() and t.dtype == torch.float64 and t.is_contiguous()):
+            if not (t.is_cuda and t.data_ptr() == dst.data_ptr() and t.dtype == torch.float64 and t.stride() == dst.stride()):
                 dst.copy_(t)                              # (H2D for host arrays; float64 kept exactly)
         x_dst = self._xbuf[:, self.halo:self.halo + B]
         in_place = blk.is_cuda and blk.dtype == torch.float32 and blk.stride() == x_dst.stride() and \
@@ -182,12 +179,11 @@ class StreamRenderer:
             raise RuntimeError("finish() before any block")
         L, nh, nb = self.tbl.L, self.nh, self._nb
         dev = self.tbl.device
-        idx_last, w_last = self._idx_all[:, nh + nb - 1:nh + nb], self._w_all[:, nh + nb - 1:nh + nb]
-        idx_all = torch.cat([self._idx_all[:, :nh], idx_last, idx_last], dim=1)
-        w_all = torch.cat([self._w_all[:, :nh], w_last, w_last], dim=1)
+        e_last, a_last = self._elev_all[:, nh + nb - 1:nh + nb], self._azim_all[:, nh + nb - 1:nh + nb]
+        elev = torch.cat([self._elev_all[:, :nh], e_last, e_last], dim=1).contiguous()
+        azim = torch.cat([self._azim_all[:, :nh], a_last, a_last], dim=1).contiguous()
         x = torch.cat([self._xbuf[:, :self.halo], torch.zeros((self.n_src, self.K), dtype=torch.float32, device=dev)], dim=1)
-        y, _ = render_params_device(x, self.K, self.S, self.tbl, idx_all.reshape(-1, 4).contiguous(),
-                                    w_all.reshape(-1, 3).contiguous(), normalize="none")
+        y, _ = render_angles_device(x, self.K, self.S, self.tbl, elev, azim, normalize="none")
         out = y[:, self.halo:self.halo + L - 1]
         self._peak_dev = torch.maximum(self._peak_dev, out.abs().max()) if out.numel() else self._peak_dev
         self._finished = True

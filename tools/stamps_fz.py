@@ -27,12 +27,12 @@ with _hip.use_library(os.path.join(ROOT, "binaural-audio-synthesis_amd", "csrc",
     buf = (ctypes.c_ulonglong * (2048 * 4 * 8))()
     lib.bas_debug_read_fz_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     assert lib.bas_debug_read_fz_stamps(buf, 2048 * 4 * 8) == 0
-a = np.array(buf, dtype=np.uint64).reshape(2048, 4, 8).astype(np.float64)
-a = a[a[:, 0, 7] > 0]
-print("workgroups:", a.shape[0], "passes per wave:", a[:, :, 7].mean())
+a = np.array(buf, dtype=np.uint64).reshape(2048 * 4, 8).astype(np.float64)
+a = a[a[:, 7] > 0]                                           # one row per wave that ran (1 or 4 per workgroup)
+print("waves:", a.shape[0], "passes per wave:", a[:, 7].mean())
 names = ["issue loads", "barrier 1", "loads->LDS", "eval + slots", "barrier 2", "FIR"]
-per_pass = a[:, :, :6] / a[:, :, 7:8]
-tot = a[:, :, 6] / a[:, :, 7]
+per_pass = a[:, :6] / a[:, 7:8]
+tot = a[:, 6] / a[:, 7]
 for i, nm in enumerate(names):
-    print(f"{nm:16s} {per_pass[:, :, i].mean() * 0.01:8.2f} us/pass   (p10 {np.percentile(per_pass[:, :, i], 10) * 0.01:.2f}, p90 {np.percentile(per_pass[:, :, i], 90) * 0.01:.2f})")
-print(f"{'whole pass':16s} {tot.mean() * 0.01:8.2f} us/pass; kernel ~ {a[:, :, 6].max() * 0.01:.1f} us")
+    print(f"{nm:16s} {per_pass[:, i].mean() * 0.01:8.2f} us/pass   (p10 {np.percentile(per_pass[:, i], 10) * 0.01:.2f}, p90 {np.percentile(per_pass[:, i], 90) * 0.01:.2f})")
+print(f"{'whole pass':16s} {tot.mean() * 0.01:8.2f} us/pass; kernel ~ {a[:, 6].max() * 0.01:.1f} us")
