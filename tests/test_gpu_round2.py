@@ -340,12 +340,12 @@ def test_stream_graph_replay_equals_plain_launches(tables, k, s, B):
 # ---------------------------------------------------------------------------
 # fused entry point: accumulate, direct output, long IRs
 # ---------------------------------------------------------------------------
-@pytest.mark.parametrize("n_src,n,l", [(1, 30000, 128), (1, 9000, 300), (6, 20000, 128), (40, 150000, 100)])
+@pytest.mark.parametrize("n_src,n,l", [(1, 30000, 128), (1, 9000, 300), (6, 20000, 128), (40, 150000, 100), (40, 6000, 128)])
 def test_fused_accumulate_and_direct_output(tables, n_src, n, l):
     """bas_render_mix_fused_f32 called directly: rendering the sources in two calls, the second with accumulate = 1,
     equals one call (and the oracle), and the reported peak is max|y| of the sum.  One source takes the direct-output
     form (no slabs; also with three tap segments at L = 300), several sources the slab + reduce form (40 x 150 000:
-    tiles of 8192)."""
+    tiles of 8192; 40 x 6 000: 41 parts per tile, summed by the wide reduce kernel)."""
     import torch
     from binaural_audio_synthesis_amd import _hip
     h = tables["consistent"].truncated(l)
