@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     constexpr int XFLOATS = 8 * XR * 4;
     constexpr int MAXEV = NW == 4 ? 6 : 7;                   // chunk IRs one wave evaluates (its slots + 1)
     static_assert(XR % 2 == 1, "x image rows must be odd");
+    static_assert(NW != 1 || MAXEV * 2 * BAS_PLANS_WORDS <= HD_SLOT, "NW = 1: the plans must fit the last chunk slot");
     extern __shared__ f32x4 lds4[];
     f32x4 *xs4 = lds4;                                       // [8][XR] float4
     float *hd = reinterpret_cast<float *>(lds4) + XFLOATS;   // [nslots][HD_SLOT]: (h0_L, h0_R, d_L, d_R) per tap
@@ -330,7 +331,9 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         FZ_STAMP_NW(t2);
 
         // ---- registers -> LDS: plans into this wave's own region, the x window as a column-major image
-        f32x4 *plw = reinterpret_cast<f32x4 *>(hd + A.nslots * HD_SLOT) + wv * (MAXEV * PL4);
+        // (NW = 1: the plans overlay the last chunk slot, which this wave writes only after its last plan read)
+        f32x4 *plw = NW == 1 ? reinterpret_cast<f32x4 *>(hd + (A.nslots - 1) * HD_SLOT)
+                             : reinterpret_cast<f32x4 *>(hd + A.nslots * HD_SLOT) + wv * (MAXEV * PL4);
 #pragma unroll
         for (int r = 0; r < 2; ++r)
             if (lane + 64 * r < n_ev * PL4) plw[lane + 64 * r] = pv[r];
@@ -507,9 +510,31 @@ struct FzPlan {
     size_t lds_bytes, slab_bytes;
 };
 
-static int fz_slots(int nw, int K) {                         // chunk slots a window of this tile can touch
+static int fz_slots(int nw, int K) {                         // chunk slots a window of this tile can touch (any alignment)
     const int rows = 2048 * nw / 32 + HD_HALO;
     return (K - 32 + 32 * (rows - 1)) / K + 1;
+}
+
+// The same for the windows that really occur: tile t, tap segment sg start at t * tile - 128 sg - 32 halo, whose offset
+// inside its chunk repeats with period K / gcd(tile, K) - chunk sizes that divide the tile (512, 1024, ..) always start
+// 128 samples before a chunk boundary and need one slot less than the worst case.
+static int fz_slots_exact(int nw, int K, int Lp, long n_tiles) {
+    const long tile = 2048L * nw;
+    const int nseg = (Lp + RT_SEG - 1) / RT_SEG;
+    int worst = 1;
+    const long t_max = n_tiles < K ? n_tiles : K;
+    for (long t = 0; t < t_max; ++t) {
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int Lseg = Lp - sg * RT_SEG < RT_SEG ? Lp - sg * RT_SEG : RT_SEG;
+            const int halo = (Lseg + 31) >> 5;
+            const long xbase = t * tile - (long)sg * RT_SEG - 32L * halo;
+            long mo = xbase % K;
+            if (mo < 0) mo += K;
+            const int slots = (int)((mo + 32L * (tile / 32 + halo - 1)) / K) + 1;
+            if (slots > worst) worst = slots;
+        }
+    }
+    return worst;
 }
 
 static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
@@ -529,12 +554,14 @@ static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
 #ifdef BAS_DIAG
         if (force_nw && atoi(force_nw) != nw) continue;
 #endif
-        const int nslots = fz_slots(nw, K);
+        const long n_tiles_nw = (T_out + 2048L * nw - 1) / (2048L * nw);
+        const int nslots = fz_slots_exact(nw, K, (L + 7) & ~7, n_tiles_nw);
         const int maxev = nw == 4 ? 6 : 7;
         const int spw = (nslots + nw - 1) / nw;
         if (spw + 1 > maxev) continue;
         const int rows = 2048 * nw / 32 + HD_HALO;
-        const size_t lds = (size_t)(8 * (rows + 1) * 4 + nslots * HD_SLOT + nw * maxev * 2 * BAS_PLANS_WORDS) * sizeof(float);
+        // (one-wave workgroups keep their plans in the LAST slot's space: that slot is written after the last plan read)
+        const size_t lds = (size_t)(8 * (rows + 1) * 4 + nslots * HD_SLOT + (nw == 1 ? 0 : nw * maxev * 2 * BAS_PLANS_WORDS)) * sizeof(float);
         long wg_per_cu = (long)(160 * 1024 / lds);
         const long by_waves = 8 / nw;                        // two waves per SIMD (register budget of the row step)
         if (wg_per_cu > by_waves) wg_per_cu = by_waves;
