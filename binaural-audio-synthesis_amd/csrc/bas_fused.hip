@@ -38,9 +38,6 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #define FZ_ADD(slot, a, b)
 #endif
 
-#ifndef FZ_PIPE_FULL
-#define FZ_PIPE_FULL 0        // chunk-IR evaluation: 1 = two whole IRs (32 table reads) in flight, 0 = two halves (16)
-#endif
 #ifndef FZ_STAGE_PRIO
 #define FZ_STAGE_PRIO 3         // wave priority while staging (0: leave it alone)
 #endif
@@ -363,43 +360,10 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             const f32x4 *pl = plw + half * (BAS_PLANS_WORDS / 4);
             const int tq = 4 * (lane & 31) + (lane < 32 ? 2 : 0);          // first of the two taps this lane stores
             f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tq;
-#if FZ_PIPE_FULL
-            // Two chunk IRs (2 x 16 table reads) are in flight at any time: a real loop, two IRs per iteration,
-            // without vector-memory work under a branch, so that the load counters carry across iterations.
-            // Indices past the wave's last IR re-request that IR; their results are not stored.
-            FzHalf pa, pb, qa, qb;
-            f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int last = n_ev > 0 ? n_ev - 1 : 0;        // (n_ev = 0: an idle wave reads stale but in-range plan words)
-            auto plan_of = [&](int i) { return pl + (i < last ? i : last) * PL4; };
-            auto store_slot = [&](int slot, const f32x4 &h0, const f32x4 &h1) {        // (IR slot, IR slot+1 - IR slot)
-                f32x2 h0a, h0b, da, db;
-                fz_pair_ears(h0, h0a, h0b);
-                fz_pair_ears(h1 - h0, da, db);
-                if (tq < Lseg) {
-                    dst[slot * (HD_SLOT / 4)] = f32x4{h0a.x, h0a.y, da.x, da.y};
-                    dst[slot * (HD_SLOT / 4) + 1] = f32x4{h0b.x, h0b.y, db.x, db.y};
-                }
-            };
-            fz_issue<0>(tab, plan_of(0), m4, L4, pa);
-            fz_issue<1>(tab, plan_of(0), m4, L4, pb);
-            for (int i = 0; i < n_ev; i += 2) {
-                fz_issue<0>(tab, plan_of(i + 1), m4, L4, qa);
-                fz_issue<1>(tab, plan_of(i + 1), m4, L4, qb);
-                f32x4 h = fz_finish<0>(plan_of(i), pa, f32x4{0.f, 0.f, 0.f, 0.f});
-                h = fz_finish<1>(plan_of(i), pb, h) * live;
-                if (i > 0) store_slot(i - 1, prev, h);
-                fz_issue<0>(tab, plan_of(i + 2), m4, L4, pa);
-                fz_issue<1>(tab, plan_of(i + 2), m4, L4, pb);
-                f32x4 h2 = fz_finish<0>(plan_of(i + 1), qa, f32x4{0.f, 0.f, 0.f, 0.f});
-                h2 = fz_finish<1>(plan_of(i + 1), qb, h2) * live;
-                if (i + 1 < n_ev) store_slot(i, h, h2);
-                prev = h2;
-            }
-#else
             FzHalf ha, hb;
             f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
-            fz_issue<0>(tab, pl, m4, L4, ha);                // (n_ev = 0: reads stale plan words of an idle wave:
-            const f32x4 *pl_last = pl + (n_ev > 0 ? n_ev - 1 : 0) * PL4;          //  in-range offsets, nothing stored)
+            const f32x4 *pl_last = pl + (n_ev > 0 ? n_ev - 1 : 0) * PL4;
+            if (n_ev > 0) fz_issue<0>(tab, pl, m4, L4, ha);  // (a wave without slots - few, long chunks - skips it all)
             // a real loop without branches in its body: the load counters then carry across iterations and each
             // half is folded while the next one is in flight (the last iteration re-requests its own first half)
             for (int i = 0; i < n_ev; ++i) {
@@ -420,7 +384,6 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                 prev = h;
                 pl = pl_next;
             }
-#endif
         }
         FZ_STAMP(t4);
         __syncthreads();
@@ -537,7 +500,29 @@ static int fz_slots_exact(int nw, int K, int Lp, long n_tiles) {
     return worst;
 }
 
+static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L);
+
+// The plan of a shape is asked for three times per render (supported?, workspace size, launch) and the streaming
+// renderer renders the same shape block after block: remember the last one per thread.
 static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
+    struct Key {
+        int n_src, K, S, L, cus;
+        long T_in;
+    };
+    static thread_local Key last_key = {-1, 0, 0, 0, 0, 0};
+    static thread_local FzPlan last_plan = {};
+    const int cus = bas_device_cus();
+#ifndef BAS_DIAG                                             // (the diagnostic build's BAS_FZ_NW may change between calls)
+    if (last_key.n_src == n_src && last_key.T_in == T_in && last_key.K == K && last_key.S == S && last_key.L == L &&
+        last_key.cus == cus)
+        return last_plan;
+#endif
+    last_plan = fz_plan_uncached(n_src, T_in, K, S, L);
+    last_key = Key{n_src, K, S, L, cus, T_in};
+    return last_plan;
+}
+
+static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
     FzPlan p = {};
     if (n_src <= 0 || T_in <= 0 || K < 32 || K % 32 != 0 || S % 32 != 0 || K % S != 0 || L <= 0) return p;
     if (fz_slots(4, K) > FZ_MAXSLOTS) return p;              // K >= 448 or so
