@@ -62,8 +62,9 @@ def _load(path):
         raise RuntimeError(
             f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C {os.path.dirname(path)}`.  There is no CPU fallback.")
-    handle = ctypes.CDLL(path)
-    for name, (res, args) in SIGNATURES.items():
+    import torch                                # noqa: F401  first: PyTorch-ROCm brings its own libamdhip64, and the library
+    handle = ctypes.CDLL(path)                  # must bind to THAT runtime (loaded the other way round a second HIP runtime
+    for name, (res, args) in SIGNATURES.items():   # comes up beside torch's and sees no device)
         fn = getattr(handle, name)              # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
     if handle.bas_version() != ABI_VERSION:

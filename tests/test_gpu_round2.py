@@ -394,3 +394,17 @@ def test_fused_accumulate_and_direct_output(tables, n_src, n, l):
     scale = float(expect.abs().max())
     assert float((y_two - expect).abs().max()) <= 2e-6 * scale
     assert abs(p_two - float(y_two.abs().max())) <= 1e-6 * scale
+
+
+def test_fused_path_random_shapes():
+    """tools/stress_fused.py: random IR lengths (1 .. 300), chunk sizes 448 .. 4096, subchunks 32 .. 256, 1 .. 47 sources,
+    signals up to 160 000 samples, random trajectories on the adversarial table - the fused kernel in both tile sizes,
+    direct output, slab and wide reduce, one to three tap segments - against the oracle's whole-signal render."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_fused.py"), "24", "3"], capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("worst") and "tile8192" in last and "tile2048" in last, last
