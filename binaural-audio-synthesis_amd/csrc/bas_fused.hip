@@ -74,53 +74,6 @@ struct FzArgs {
     long T_out;
 };
 
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-// Taps m .. m+3 of one chunk IR for this lane's ear: h[m] = sum_k w_k * sample_k(m), 16 table reads in 4 sets
-// (reads 0-4, 5-8, 9-12, 13-15; one wrapped lane offset per set).  pl = this half-wave's plan in LDS (9 x 16
-// bytes: off[16], w[16], o4[4]): all lanes of a half-wave read the same addresses, so those reads are broadcasts.
-// The work is cut in halves of 8 reads so that the caller can keep the loads of the next half in flight while
-// it folds the current one (the compiler, left alone, serialises the loads once registers get tight).
-struct FzHalf {
-    u32x4 v[8];
-};
-
-__device__ __forceinline__ unsigned fz_wrap(unsigned m4, unsigned o4, unsigned L4) {
-    const unsigned idx = m4 + o4;                              // 4 (m + o): m < L, o < L
-    const unsigned wr = idx - L4;
-    return idx < wr ? idx : wr;                                // idx >= 4 L ? idx - 4 L : idx
-}
-
-template <int HSEL>
-__device__ __forceinline__ void fz_issue(__amdgpu_buffer_rsrc_t tab, const f32x4 *__restrict__ pl, unsigned m4,
-                                          unsigned L4, FzHalf &H) {
-    const u32x4 o4 = __builtin_bit_cast(u32x4, pl[8]);
-    const u32x4 pa = __builtin_bit_cast(u32x4, pl[2 * HSEL]), pb = __builtin_bit_cast(u32x4, pl[2 * HSEL + 1]);
-    unsigned a[8];
-    if (HSEL == 0) {                                           // reads 0-4: set 0, reads 5-7: set 1
-        const unsigned s0 = fz_wrap(m4, o4.x, L4), s1 = fz_wrap(m4, o4.y, L4);
-        a[0] = s0 + pa.x; a[1] = s0 + pa.y; a[2] = s0 + pa.z; a[3] = s0 + pa.w;
-        a[4] = s0 + pb.x; a[5] = s1 + pb.y; a[6] = s1 + pb.z; a[7] = s1 + pb.w;
-    } else {                                                   // read 8: set 1, reads 9-12: set 2, reads 13-15: set 3
-        const unsigned s1 = fz_wrap(m4, o4.y, L4), s2 = fz_wrap(m4, o4.z, L4), s3 = fz_wrap(m4, o4.w, L4);
-        a[0] = s1 + pa.x; a[1] = s2 + pa.y; a[2] = s2 + pa.z; a[3] = s2 + pa.w;
-        a[4] = s2 + pb.x; a[5] = s3 + pb.y; a[6] = s3 + pb.z; a[7] = s3 + pb.w;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) H.v[j] = __builtin_amdgcn_raw_buffer_load_b128(tab, (int)a[j], 0, 0);
-}
-
-template <int HSEL>
-__device__ __forceinline__ f32x4 fz_finish(const f32x4 *__restrict__ pl, const FzHalf &H, f32x4 acc) {
-    const f32x4 wa = pl[4 + 2 * HSEL], wb = pl[5 + 2 * HSEL];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float w = j < 4 ? wa[j] : wb[j - 4];
-        acc = __builtin_elementwise_fma(__builtin_bit_cast(f32x4, H.v[j]), f32x4{w, w, w, w}, acc);
-    }
-    return acc;
-}
-
 // Lanes l < 32 hold four taps of the left ear, lanes l + 32 the same taps of the right ear.  After two half-wave
 // swaps lane l holds taps 2, 3 of both ears and lane l + 32 taps 0, 1 of both ears: (t_a L, t_a R), (t_b L, t_b R).
 __device__ __forceinline__ void fz_pair_ears(const f32x4 &h, f32x2 &ta, f32x2 &tb) {

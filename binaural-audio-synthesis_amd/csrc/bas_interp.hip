@@ -184,13 +184,12 @@ __device__ __forceinline__ void ring_plan(RingPlan &rp, const double *__restrict
 // 16 loads off scalar bases and 16 FMAs with scalar weights.
 #define BAS_QB 16      // queries per workgroup
 
-// plan kernel: one thread per (query, ear).  SCALAR: write the plan as EarPlanS (for bas_render_mix_fused_f32)
-template <bool SCALAR>
+// plan kernel: one thread per (query, ear)
 __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__restrict__ diffs,
                                                                   const int32_t *__restrict__ idx,
                                                                   const double *__restrict__ w, int n,
                                                                   int ndir, int L, int U,
-                                                                  void *__restrict__ plans_out) {
+                                                                  EarPlanS *__restrict__ plans) {
     const long t = blockIdx.x * 256L + threadIdx.x;
     if (t >= 2L * n) return;
     const long q = t >> 1;
@@ -213,11 +212,27 @@ __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__
     const int c_top = bas_submod(0, b4, M);
     ring_plan(top, d, e, ndir, pt, qt, at, L, U, c_top, s2);
     ring_plan(bot, d, e, ndir, pb, qb, ab, L, U, bas_submod(c_top, b3, M), s2);
-    EarPlanW pl;
-    make_set(pl.set[0], bot.row_q, bot.c_q, L, U, qb);
-    make_set(pl.set[1], bot.row_p, bot.c_p, L, U, pb);
-    make_set(pl.set[2], top.row_q, top.c_q, L, U, qt);
-    make_set(pl.set[3], top.row_p, top.c_p, L, U, pt);
+    // the four read sets: (packed row, offset c of read 0 in upsampled samples); read j of a set sits at c - j
+    const int set_row[4] = {bot.row_q, bot.row_p, top.row_q, top.row_p};
+    const int set_c[4] = {bot.c_q, bot.c_p, top.c_q, top.c_p};
+    const int nset[4] = {5, 4, 4, 3};
+    EarPlanS ps;
+    int k = 0;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const int o = set_c[st] / U, ph0 = set_c[st] - o * U;                 // c in [0, M)
+        const int base = set_row[st] + ph0 * BAS_PLANE(L) + 1;                // float index of plane ph0's sample 0
+        ps.o4[st] = 4u * (unsigned)o;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            if (j < nset[st]) {
+                // read j <= ph0: plane ph0 - j; beyond: plane ph0 - j + U one sample earlier (guards make -1 safe)
+                const int pb = j <= ph0 ? base - j * BAS_PLANE(L) : base + (U - j) * BAS_PLANE(L) - 1;
+                ps.off[k] = 4u * (unsigned)pb;
+                ++k;
+            }
+        }
+    }
     // fold the blend chain into 16 weights (apply_hrtf.py:90-91, :98-99, :268-269, :276-277)
     const double cC[2] = {1.0 - (double)f4, (double)f4};
     double wrb[3], wbb[4], wbt[3];
@@ -227,93 +242,73 @@ __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__
         const double h = (double)bot.f2;
         wbb[0] = wrb[0] * (1.0 - h); wbb[1] = wrb[0] * h + wrb[1] * (1.0 - h);
         wbb[2] = wrb[1] * h + wrb[2] * (1.0 - h); wbb[3] = wrb[2] * h;
-        const double k = (double)bot.f1;
-        pl.w[0] = (float)(ab * wbb[0] * (1.0 - k));
-        pl.w[1] = (float)(ab * (wbb[0] * k + wbb[1] * (1.0 - k)));
-        pl.w[2] = (float)(ab * (wbb[1] * k + wbb[2] * (1.0 - k)));
-        pl.w[3] = (float)(ab * (wbb[2] * k + wbb[3] * (1.0 - k)));
-        pl.w[4] = (float)(ab * wbb[3] * k);
+        const double kk = (double)bot.f1;
+        ps.w[0] = (float)(ab * wbb[0] * (1.0 - kk));
+        ps.w[1] = (float)(ab * (wbb[0] * kk + wbb[1] * (1.0 - kk)));
+        ps.w[2] = (float)(ab * (wbb[1] * kk + wbb[2] * (1.0 - kk)));
+        ps.w[3] = (float)(ab * (wbb[2] * kk + wbb[3] * (1.0 - kk)));
+        ps.w[4] = (float)(ab * wbb[3] * kk);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pl.w[5 + j] = (float)((1.0 - ab) * wbb[j]);
+        for (int j = 0; j < 4; ++j) ps.w[5 + j] = (float)((1.0 - ab) * wbb[j]);
     }
     {
         const double r0 = a * cC[0], r1 = a * cC[1], h = (double)top.f2;
         wbt[0] = r0 * (1.0 - h); wbt[1] = r0 * h + r1 * (1.0 - h); wbt[2] = r1 * h;
-        const double k = (double)top.f1;
-        pl.w[9] = (float)(at * wbt[0] * (1.0 - k));
-        pl.w[10] = (float)(at * (wbt[0] * k + wbt[1] * (1.0 - k)));
-        pl.w[11] = (float)(at * (wbt[1] * k + wbt[2] * (1.0 - k)));
-        pl.w[12] = (float)(at * wbt[2] * k);
+        const double kk = (double)top.f1;
+        ps.w[9] = (float)(at * wbt[0] * (1.0 - kk));
+        ps.w[10] = (float)(at * (wbt[0] * kk + wbt[1] * (1.0 - kk)));
+        ps.w[11] = (float)(at * (wbt[1] * kk + wbt[2] * (1.0 - kk)));
+        ps.w[12] = (float)(at * wbt[2] * kk);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) pl.w[13 + j] = (float)((1.0 - at) * wbt[j]);
+        for (int j = 0; j < 3; ++j) ps.w[13 + j] = (float)((1.0 - at) * wbt[j]);
     }
-    if (SCALAR) {
-        EarPlanS ps;
-        const int nset[4] = {5, 4, 4, 3};
-        int k = 0;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const SetPlan &sp = pl.set[st];
-            ps.o4[st] = 4u * (unsigned)sp.o;
-#pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                if (j < nset[st]) {
-                    // read j <= ph0: plane ph0 - j; beyond: plane ph0 - j + U one sample earlier (bas_plan.h set_dot)
-                    const int pb = j <= sp.ph0 ? sp.base - j * BAS_PLANE(L) : sp.base + (U - j) * BAS_PLANE(L) - 1;
-                    ps.off[k] = 4u * (unsigned)pb;
-                    ps.w[k] = pl.w[k];
-                    ++k;
-                }
-            }
-        }
-        reinterpret_cast<EarPlanS *>(plans_out)[t] = ps;
-    } else {
-        reinterpret_cast<EarPlanW *>(plans_out)[t] = pl;
-    }
+    plans[t] = ps;
 }
 
-// eval kernel: one wave per (query, ear).  The 128-byte plan is fetched with ONE coalesced vector
-// load (lane k = word k; the scalar cache cannot stream 57 MB of plans) and spread into SGPRs with
-// v_readlane; the next row's plan is requested before the current row is evaluated.
-static_assert(sizeof(EarPlanW) == 128, "one plan = 32 words = one 128-byte load per wave");
-
-__global__ __launch_bounds__(256) void bas_interp2d_eval_kernel(const float *__restrict__ packed,
-                                                                  const EarPlanW *__restrict__ plans,
-                                                                  long n_rows, int L, int U,
-                                                                  float *__restrict__ H) {
-    // A wave evaluates TWO consecutive rows (= the two ears of a query): lanes 0-31 the first, lanes
-    // 32-63 the second, 4 adjacent taps per lane.  16-byte loads run the vector L1 at its full
-    // 64 B/clk; the 8-byte form of this kernel was bound by address processing at half that rate.
+// eval kernel: a wave per query (both ears), grid-stride.  The wave copies the query's two plans (288 bytes) into its
+// own LDS region; lanes 0-31 then evaluate four adjacent taps of the left ear, lanes 32-63 of the right: every plan
+// value reaches its half-wave as a broadcast LDS read (bas_plan.h).  Sixteen 16-byte table reads per lane in two halves
+// of 8, the second in flight while the first is folded; the next query's plans are requested before this one is evaluated.
+__global__ __launch_bounds__(256) void bas_interp2d_eval_kernel(const float *__restrict__ packed, unsigned packed_bytes,
+                                                                  const EarPlanS *__restrict__ plans, long n_queries,
+                                                                  int L, float *__restrict__ H) {
+    constexpr int PL4 = 2 * BAS_PLANS_WORDS / 4;             // float4 per query (18)
+    __shared__ f32x4 pl_lds[4][PL4];
     const int lane = threadIdx.x & 63;
     const int half = lane >> 5;
-    const long pair0 = rfl((int)(threadIdx.x >> 6)) + blockIdx.x * 4L;
-    const long n_pairs = (n_rows + 1) >> 1;
+    const int wv = rfl((int)(threadIdx.x >> 6));
+    const __amdgpu_buffer_rsrc_t tab =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packed), 0, (int)packed_bytes, 0x00020000);
+    const unsigned L4 = 4u * (unsigned)L;
+    const f32x4 *pl_src = reinterpret_cast<const f32x4 *>(plans);
     const long stride = gridDim.x * 4L;
-    const int *pw = reinterpret_cast<const int *>(plans);
-    auto fetch = [&](long pr) {                               // one coalesced 256-byte load: both plans
-        long r = 2 * pr + half;
-        if (r > n_rows - 1) r = n_rows - 1;
-        return pw[r * 32 + (lane & 31)];
-    };
-    int word_next = pair0 < n_pairs ? fetch(pair0) : 0;
-    for (long pr = pair0; pr < n_pairs; pr += stride) {
-        const int word = word_next;
-        word_next = fetch(pr + stride < n_pairs ? pr + stride : pr);
-        const long row = 2 * pr + half;
-        float *Hq = H + (row < n_rows ? row : n_rows - 1) * L;
+    long q = blockIdx.x * 4L + wv;
+    const int piece = lane < PL4 ? lane : 0;
+    f32x4 next = q < n_queries ? pl_src[q * PL4 + piece] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (; q < n_queries; q += stride) {
+        if (lane < PL4) pl_lds[wv][lane] = next;
+        __builtin_amdgcn_wave_barrier();                     // the other lanes of this wave read these words below
+        const long qn = q + stride < n_queries ? q + stride : q;
+        next = pl_src[qn * PL4 + piece];
+        const f32x4 *pl = pl_lds[wv] + half * (BAS_PLANS_WORDS / 4);
+        float *Hrow = H + (2 * q + half) * L;
         for (int m0 = 0; m0 < L; m0 += 128) {                // 32 lanes x 4 taps per sweep
             const int m = m0 + 4 * (lane & 31);
             const int m_c = m < L ? m : L - 1;               // idle lanes evaluate a valid tap and drop it
-            const f32x4 acc = plan_eval_quad(packed, word, half, m_c, L, U);
-            if (row < n_rows) {
-                if (m + 3 < L) *reinterpret_cast<f32x4_a4 *>(Hq + m) = acc;
-                else {
-                    if (m < L) Hq[m] = acc.x;
-                    if (m + 1 < L) Hq[m + 1] = acc.y;
-                    if (m + 2 < L) Hq[m + 2] = acc.z;
-                }
+            const unsigned m4 = 4u * (unsigned)m_c;
+            FzHalf ha, hb;
+            fz_issue<0>(tab, pl, m4, L4, ha);
+            fz_issue<1>(tab, pl, m4, L4, hb);
+            f32x4 acc = fz_finish<0>(pl, ha, f32x4{0.f, 0.f, 0.f, 0.f});
+            acc = fz_finish<1>(pl, hb, acc);
+            if (m + 3 < L) *reinterpret_cast<f32x4_a4 *>(Hrow + m) = acc;
+            else {
+                if (m < L) Hrow[m] = acc.x;
+                if (m + 1 < L) Hrow[m + 1] = acc.y;
+                if (m + 2 < L) Hrow[m + 2] = acc.z;
             }
         }
+        __builtin_amdgcn_wave_barrier();                     // (the next iteration overwrites the plan words)
     }
 }
 
@@ -363,10 +358,10 @@ __global__ __launch_bounds__(256) void bas_interp2d_generic_kernel(const float *
     }
 }
 
-static_assert(sizeof(EarPlanS) == 4 * BAS_PLANS_WORDS && sizeof(EarPlanS) >= sizeof(EarPlanW), "plan sizes");
+static_assert(sizeof(EarPlanS) == 4 * BAS_PLANS_WORDS && sizeof(EarPlanS) % 16 == 0, "a plan = 9 pieces of 16 bytes");
 
 extern "C" size_t bas_interp2d_workspace_bytes(int n) {
-    return n > 0 ? (size_t)n * 2 * sizeof(EarPlanS) + 16 : 16;     // the larger of the two plan forms
+    return n > 0 ? (size_t)n * 2 * sizeof(EarPlanS) + 16 : 16;
 }
 
 extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double *w, int n, int ndir,
@@ -384,8 +379,8 @@ extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, co
                 BAS_E_WORKSPACE, "bas_interp2d_plan_f32: 16-byte aligned buffer of %zu bytes needed, %zu given",
                 bas_interp2d_workspace_bytes(n), plans_bytes);
     const long rows = 2L * n;
-    hipLaunchKernelGGL(bas_interp2d_plan_kernel<true>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                       bas_stream(stream), diffs, idx, w, n, ndir, L, U, plans);
+    hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       bas_stream(stream), diffs, idx, w, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans));
     return bas_check_launch("bas_interp2d_plan_f32");
 }
 
@@ -400,7 +395,7 @@ extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const 
     BAS_REQUIRE(ws && ws_bytes >= bas_interp2d_workspace_bytes(n) && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
                 BAS_E_WORKSPACE, "bas_interp2d_f32: 16-byte aligned workspace of %zu bytes needed, %zu given",
                 bas_interp2d_workspace_bytes(n), ws_bytes);
-    EarPlanW *plans = reinterpret_cast<EarPlanW *>(ws);
+    EarPlanS *plans = reinterpret_cast<EarPlanS *>(ws);
     hipStream_t st = bas_stream(stream);
     const long rows = 2L * n;
     if (U < BAS_PLAN_MIN_U) {                                // small upsampling factors: plain evaluation
@@ -410,14 +405,15 @@ extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const 
                            w, (long)n, ndir, L, U, H);
         return bas_check_launch("bas_interp2d_f32(generic)");
     }
-    hipLaunchKernelGGL(bas_interp2d_plan_kernel<false>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
+    hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
                        w, n, ndir, L, U, plans);
     int rc = bas_check_launch("bas_interp2d_f32(plan)");
     if (rc) return rc;
-    long blocks = ((rows + 1) / 2 + 3) / 4;
+    long blocks = ((long)n + 3) / 4;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(bas_interp2d_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, plans, rows, L, U,
-                       H);
+    const unsigned table_bytes = (unsigned)((size_t)2 * ndir * U * BAS_PLANE(L) * sizeof(float));
+    hipLaunchKernelGGL(bas_interp2d_eval_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packed, table_bytes, plans,
+                       (long)n, L, H);
     return bas_check_launch("bas_interp2d_f32(eval)");
 }
 
