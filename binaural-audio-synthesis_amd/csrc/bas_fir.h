@@ -94,3 +94,74 @@ __device__ __forceinline__ void hd_row_step_x(f32x2 (&acc)[32], const float (&xr
 #undef HD_MASKED_OCTET
 }
 
+// ---------------------------------------------------------------------------
+// The same row step as a 2-parallel fast FIR (polyphase split of outputs, inputs and taps into even / odd):
+//   y[2p]   = A[p] + B[p-1]              A = g_e * x_e,  B = g_o * x_o,  P = (g_e + g_o) * (x_e + x_o)
+//   y[2p+1] = P[p] - A[p] - B[p]         (three half-rate products instead of four: 784 packed FMAs per 32 x 32
+//                                          block instead of 1024, + 32 adds forming g_e + g_o, + 16 forming x_e + x_o)
+// A, B (17 entries: p = -1 .. 15) and P are accumulated over all row steps, sources and tap segments of a tile and
+// only combined when the tile is flushed (ffa_combine).  Every product is linear in g, so the per-row crossfade
+// g = h0 + al d is formed per octet exactly as in the direct form.  Rounding differs from the direct sum by a few
+// 1e-8 of the output's norm (tests: 1e-5).
+__device__ __forceinline__ void ffa_zero(f32x2 (&fa)[16], f32x2 (&fb)[17], f32x2 (&fp)[16]) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) fa[p] = fp[p] = f32x2{0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 17; ++p) fb[p] = f32x2{0.f, 0.f};
+}
+
+__device__ __forceinline__ void ffa_combine(f32x2 (&out)[32], const f32x2 (&fa)[16], const f32x2 (&fb)[17],
+                                             const f32x2 (&fp)[16]) {
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        out[2 * p] = fa[p] + fb[p];                          // fb[p] holds B[p-1]
+        out[2 * p + 1] = (fp[p] - fa[p]) - fb[p + 1];
+    }
+}
+
+// one octet of taps: full-rate taps 8 I + j - 32 (relative to the row distance) = half-rate taps dk = 4 I + jj - 16
+// of g_e (j even) and g_o (j odd)
+template <int I>
+__device__ __forceinline__ void ffa_octet_fma(f32x2 (&fa)[16], f32x2 (&fb)[17], f32x2 (&fp)[16], const float (&xr)[32],
+                                               const float (&xs)[16], const f32x4 (&hv)[8], float al) {
+    f32x2 ge[4], go[4], gs[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        ge[jj] = __builtin_elementwise_fma(f32x2{hv[2 * jj].z, hv[2 * jj].w}, f32x2{al, al},
+                                           f32x2{hv[2 * jj].x, hv[2 * jj].y});
+        go[jj] = __builtin_elementwise_fma(f32x2{hv[2 * jj + 1].z, hv[2 * jj + 1].w}, f32x2{al, al},
+                                           f32x2{hv[2 * jj + 1].x, hv[2 * jj + 1].y});
+        gs[jj] = ge[jj] + go[jj];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int dk = 4 * I + jj - 16;                      // p - q
+#pragma unroll
+        for (int p = -1; p < 16; ++p) {
+            const int q = p - dk;
+            if (q >= 0 && q < 16) {
+                if (p >= 0) {
+                    fma2(fa[p], xr[2 * q], ge[jj]);
+                    fma2(fp[p], xs[q], gs[jj]);
+                }
+                fma2(fb[p + 1], xr[2 * q + 1], go[jj]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void ffa_row_step_x(f32x2 (&fa)[16], f32x2 (&fb)[17], f32x2 (&fp)[16], const float (&xr)[32],
+                                                const float *__restrict__ hdrow, float al, unsigned live_mask) {
+    float xs[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xs[q] = xr[2 * q] + xr[2 * q + 1];
+    f32x4 hv[8];
+#define FFA_MASKED_OCTET(I)                           \
+    if (live_mask & (1u << I)) {                      \
+        hd_load_octet<false>(hv, hdrow, I);           \
+        ffa_octet_fma<I>(fa, fb, fp, xr, xs, hv, al); \
+    }
+    FFA_MASKED_OCTET(0) FFA_MASKED_OCTET(1) FFA_MASKED_OCTET(2) FFA_MASKED_OCTET(3)
+    FFA_MASKED_OCTET(4) FFA_MASKED_OCTET(5) FFA_MASKED_OCTET(6) FFA_MASKED_OCTET(7)
+#undef FFA_MASKED_OCTET
+}

@@ -50,6 +50,9 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #ifndef FZ_NT_LOADS
 #define FZ_NT_LOADS 0            // x window, plans and slabs are touched once: non-temporal, so that L2 keeps the table
 #endif
+#ifndef FZ_FFA
+#define FZ_FFA 1                // row step as a 2-parallel fast FIR (bas_fir.h: 3/4 of the FMAs); 0: direct form
+#endif
 #define FZ_MAXSLOTS 20          // chunk slots under one tile (LDS: two 4-wave workgroups per CU at K >= 448)
 
 // (the four arrays are separate __restrict__ kernel parameters, not members: only then can the compiler prove
@@ -127,9 +130,16 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     if (!A.direct && peak_bits && blockIdx.x == 0 && tid == 0) *peak_bits = 0u;   // the reduce kernel maxes into it later
     if (n_pass <= 0) return;
 
+#if FZ_FFA
+    f32x2 fa[16], fb[17], fp[16];                            // half-rate partial sums (bas_fir.h), combined in flush()
+    ffa_zero(fa, fb, fp);
+#define FZ_ACC_CLEAR() ffa_zero(fa, fb, fp)
+#else
     f32x2 acc[32];
-#pragma unroll
-    for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+#define FZ_ACC_CLEAR()                                        \
+    _Pragma("unroll") for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f}
+    FZ_ACC_CLEAR();
+#endif
 
     const long first_tile = unit0 / A.n_src;
     float *slab_wg = slab + (long)blockIdx.x * A.parts_per_wg * 2 * TILE;
@@ -139,6 +149,10 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     const unsigned L4 = 4u * (unsigned)A.L;
 
     auto flush = [&](long tile) {
+#if FZ_FFA
+        f32x2 acc[32];
+        ffa_combine(acc, fa, fb, fp);
+#endif
         if (A.direct) {                                      // uniform
             const long n0 = tile * TILE + 2048 * wv + 32 * lane;        // this lane's first output
             float lmax = 0.f;
@@ -172,8 +186,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                 for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
                 if (lane == 0) atomicMax(peak_bits, __float_as_uint(lmax));
             }
-#pragma unroll
-            for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+            FZ_ACC_CLEAR();
             return;
         }
         float *dst = slab_wg + (tile - first_tile) * 2 * TILE + 2048 * wv + 32 * lane;
@@ -189,8 +202,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             r4[i] = f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y};
 #endif
         }
-#pragma unroll
-        for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+        FZ_ACC_CLEAR();
     };
 
     // scalar state of the walk over (tile, source, tap segment): advanced by counters, never re-divided
@@ -378,7 +390,11 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             }
             float xr[32];
             fz_load_xrow<XR>(xr, xrow);
+#if FZ_FFA
+            ffa_row_step_x(fa, fb, fp, xr, hd + sl * HD_SLOT + (32 * rp - 32) * 4, al[0], mk);
+#else
             hd_row_step_x<1, false>(acc, xr, hd + sl * HD_SLOT + (32 * rp - 32) * 4, al, mk);
+#endif
             xrow -= 1;
             m_in -= 32;
             if (m_in < 0) {

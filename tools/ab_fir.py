@@ -64,7 +64,7 @@ for rnd in range(args.rounds + 1):
             else:
                 scale = float(ref.abs().max())
                 err = float((y - ref).abs().max()) / scale if scale > 0 else float(y.abs().max())
-                assert err < 2e-6, (name, err)
+                assert err < 1e-5, (name, err)          # (builds may differ in summation order: the tests' tolerance)
             if rnd > 0:
                 res[name][0].append(sum(ms) / len(ms)); res[name][1].append(el)
 for name, (km, st) in res.items():
