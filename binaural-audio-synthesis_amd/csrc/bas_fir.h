@@ -150,6 +150,7 @@ __device__ __forceinline__ void ffa_octet_fma(f32x2 (&fa)[16], f32x2 (&fb)[17], 
     }
 }
 
+template <bool HONLY = false>
 __device__ __forceinline__ void ffa_row_step_x(f32x2 (&fa)[16], f32x2 (&fb)[17], f32x2 (&fp)[16], const float (&xr)[32],
                                                 const float *__restrict__ hdrow, float al, unsigned live_mask) {
     float xs[16];
@@ -158,7 +159,7 @@ __device__ __forceinline__ void ffa_row_step_x(f32x2 (&fa)[16], f32x2 (&fb)[17],
     f32x4 hv[8];
 #define FFA_MASKED_OCTET(I)                           \
     if (live_mask & (1u << I)) {                      \
-        hd_load_octet<false>(hv, hdrow, I);           \
+        hd_load_octet<HONLY>(hv, hdrow, I);           \
         ffa_octet_fma<I>(fa, fb, fp, xr, xs, hv, al); \
     }
     FFA_MASKED_OCTET(0) FFA_MASKED_OCTET(1) FFA_MASKED_OCTET(2) FFA_MASKED_OCTET(3)

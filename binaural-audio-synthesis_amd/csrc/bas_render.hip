@@ -465,9 +465,14 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
     unsigned long long st_fir = 0;
 #endif
 
+    // one alpha per whole row (NSUB = 1, no multi-part rows): the row step runs as a 2-parallel fast FIR on half-rate partial sums that
+    // are combined into the 32 outputs when the tile is flushed (bas_fir.h); otherwise the direct form on acc
+    constexpr bool FFA = NSUB == 1 && !DUAL;            // (multi-part rows hold too much other state: 200 spilled registers)
     f32x2 acc[32];
+    f32x2 fa[16], fb[17], fp[16];
 #pragma unroll
     for (int o = 0; o < 32; ++o) acc[o] = f32x2{0.f, 0.f};
+    ffa_zero(fa, fb, fp);
 
     const long first_tile = unit0 / A.n_src;
     long cur_tile = first_tile;
@@ -484,6 +489,10 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
         float *dst = slab_wg + (tile - first_tile) * 2 * HD_TILE + 2048 * wv + 32 * lane;
         f32x4 *l4 = reinterpret_cast<f32x4 *>(dst);
         f32x4 *r4 = reinterpret_cast<f32x4 *>(dst + HD_TILE);
+        if constexpr (FFA) {
+            ffa_combine(acc, fa, fb, fp);
+            ffa_zero(fa, fb, fp);
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             l4[i] = f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x};
@@ -707,7 +716,13 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                 float al[NSUB];
                 const float *hdrow;
                 step_setup(rp, al, hdrow);
-                hd_row_step_masked<NSUB, HONLY>(acc, xrow, hdrow, al, mask_of(rp));
+                if constexpr (FFA) {
+                    float xr[32];
+                    hd_load_xrow(xr, xrow);
+                    ffa_row_step_x<HONLY>(fa, fb, fp, xr, hdrow, al[0], mask_of(rp));
+                } else {
+                    hd_row_step_masked<NSUB, HONLY>(acc, xrow, hdrow, al, mask_of(rp));
+                }
                 step_done();
             }
         }
