@@ -408,3 +408,27 @@ def test_fused_path_random_shapes():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("worst") and "tile8192" in last and "tile2048" in last, last
+
+
+@pytest.mark.parametrize("k,s,l", [(512, 32, 128), (512, 32, 100), (256, 32, 128), (1024, 64, 128)])
+def test_fast_fir_rounding_margin(tables, k, s, l):
+    """The row step of both FIR kernels is a 2-parallel fast FIR (bas_fir.h: y_odd = P - A - B): its rounding must stay
+    far inside the 1e-5 bar.  Low-pass noise is the unfriendly case (x_even ~ x_odd: P ~ 4 A); the direct float32 sum
+    of the oracle sits at ~3e-7 of the float64 result itself, so 2e-6 is asked for here."""
+    rng = np.random.default_rng(k + s + l)
+    h = tables["consistent"].truncated(l)
+    d = _device_table(h)
+    n_src, n = 3, 20000
+    white = rng.standard_normal((n_src, n + 64))
+    low = np.stack([np.convolve(w, np.ones(64) / 64, mode="valid")[:n] for w in white])       # strongly low-pass
+    sigs = np.ascontiguousarray(np.concatenate([low[:2], white[2:, :n] * 0.1]), dtype=np.float32)
+    in_length, _ = orc.render_lengths(n, k, l)
+    t = np.arange(0, in_length + 1, k, dtype=np.float64)
+    elev = rng.uniform(-0.7, 1.4, size=(n_src, t.size))
+    azim = rng.uniform(-3, 3, size=(n_src, t.size))
+    irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(t.size)]) for i in range(n_src)]
+    want = orc.render_mix(sigs, k, s, irs, normalize=False)
+    for fused in (True, False):
+        got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=fused).cpu().numpy()
+        assert got.shape == want.shape
+        assert rel_err(got, want) <= 2e-6, (fused, rel_err(got, want))
