@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__
                                                                   const double *__restrict__ w, int n,
                                                                   int ndir, int L, int U,
                                                                   EarPlanS *__restrict__ plans) {
-    const long t = blockIdx.x * 256L + threadIdx.x;
-    if (t >= 2L * n) return;
+    long t = blockIdx.x * 256L + threadIdx.x;
+    if (t >= 2L * n) t = 2L * n - 1;                         // (idle threads of the last block redo its last record: barrier below)
     const long q = t >> 1;
     const int e = (int)(t & 1);
     const int M = L * U;
@@ -262,7 +262,24 @@ __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__
 #pragma unroll
         for (int j = 0; j < 3; ++j) ps.w[13 + j] = (float)((1.0 - at) * wbt[j]);
     }
-    plans[t] = ps;
+    // 144-byte records written lane by lane would touch every 64-byte segment two or three times: the block's records go
+    // through LDS (stride 37 words: conflict-free) and leave as one contiguous run of 16-byte stores
+    __shared__ unsigned stage[256 * (BAS_PLANS_WORDS + 1)];
+    {
+        const unsigned *src = reinterpret_cast<const unsigned *>(&ps);
+        unsigned *row = stage + threadIdx.x * (BAS_PLANS_WORDS + 1);
+#pragma unroll
+        for (int i = 0; i < BAS_PLANS_WORDS; ++i) row[i] = src[i];
+    }
+    __syncthreads();
+    const long t0 = blockIdx.x * 256L;
+    const long live = 2L * n - t0 < 256 ? 2L * n - t0 : 256;            // records of this block
+    u32x4 *dst = reinterpret_cast<u32x4 *>(plans + t0);
+    for (int i = threadIdx.x; i < live * (BAS_PLANS_WORDS / 4); i += 256) {
+        const int r = i / (BAS_PLANS_WORDS / 4), c = i - r * (BAS_PLANS_WORDS / 4);
+        const unsigned *q = stage + r * (BAS_PLANS_WORDS + 1) + 4 * c;
+        dst[i] = u32x4{q[0], q[1], q[2], q[3]};
+    }
 }
 
 // eval kernel: a wave per query (both ears), grid-stride.  The wave copies the query's two plans (288 bytes) into its
