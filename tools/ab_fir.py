@@ -21,6 +21,7 @@ ap.add_argument("--fused", type=int, default=1)
 ap.add_argument("--chunk", type=int, default=512)
 ap.add_argument("--subchunk", type=int, default=32)
 ap.add_argument("--taps", type=int, default=128)
+ap.add_argument("--no-check", action="store_true", help="do not compare the outputs of the builds (diagnostic builds that compute something else on purpose)")
 ap.add_argument("--zero-x", action="store_true", help="all-zero input audio: shows how far the clock (power) limits the kernel")
 args = ap.parse_args()
 n_src, n, k, s, l = args.sources, 441000, args.chunk, args.subchunk, args.taps
@@ -64,7 +65,7 @@ for rnd in range(args.rounds + 1):
             else:
                 scale = float(ref.abs().max())
                 err = float((y - ref).abs().max()) / scale if scale > 0 else float(y.abs().max())
-                assert err < 1e-5, (name, err)          # (builds may differ in summation order: the tests' tolerance)
+                assert args.no_check or err < 1e-5, (name, err)          # (builds may differ in summation order: the tests' tolerance)
             if rnd > 0:
                 res[name][0].append(sum(ms) / len(ms)); res[name][1].append(el)
 for name, (km, st) in res.items():
