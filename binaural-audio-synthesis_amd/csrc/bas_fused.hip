@@ -48,7 +48,10 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #define FZ_START_DELAY 0        // x 10 ns: head start of the first workgroup of every CU (0: none)
 #endif
 #ifndef FZ_NT_LOADS
-#define FZ_NT_LOADS 0            // x window, plans and slabs are touched once: non-temporal, so that L2 keeps the table
+#define FZ_NT_LOADS 1           // x window and plans are read once: non-temporal, so that L2 keeps the table (same speed,
+#endif                          // 13 % fewer bytes fetched past L2)
+#ifndef FZ_NT_STORES
+#define FZ_NT_STORES 0          // non-temporal slab stores: WRITE_SIZE 40 -> 135 MB per launch - off
 #endif
 #ifndef FZ_FFA
 #define FZ_FFA 1                // row step as a 2-parallel fast FIR (bas_fir.h: 3/4 of the FMAs); 0: direct form
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         f32x4 *r4 = reinterpret_cast<f32x4 *>(dst + TILE);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-#if FZ_NT_LOADS
+#if FZ_NT_STORES
             __builtin_nontemporal_store(f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x}, l4 + i);
             __builtin_nontemporal_store(f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y}, r4 + i);
 #else
