@@ -56,6 +56,7 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #ifndef FZ_FFA
 #define FZ_FFA 1                // row step as a 2-parallel fast FIR (bas_fir.h: 3/4 of the FMAs); 0: direct form
 #endif
+#define FZ_HO_MAXEV 9           // h-only rows: chunk IRs per wave (K = 256: 35 rows under a tile of 8192)
 #define FZ_MAXSLOTS 20          // chunk slots under one tile (LDS: two 4-wave workgroups per CU at K >= 448)
 
 // (the four arrays are separate __restrict__ kernel parameters, not members: only then can the compiler prove
@@ -100,7 +101,10 @@ __device__ __forceinline__ void fz_load_xrow(float (&xr)[32], const f32x4 *__res
     }
 }
 
-template <int NW>
+// HONLY (chunk sizes below ~448: more than FZ_MAXSLOTS chunk slots under a tile): the LDS rows hold (h_L, h_R) of the
+// nslots + 1 chunk boundaries only and the row step takes d = H_{c+1} - H_c from two rows (bas_fir.h): half the LDS per
+// chunk, one more packed op per tap, and the waves evaluate disjoint sets of chunk IRs (no boundary IR twice).
+template <int NW, bool HONLY>
 __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     FzArgs A, const float *__restrict__ x,                   // [n_src] rows of T_in floats, stride A.x_stride
     float *__restrict__ slab,                                // [n_wg][parts_per_wg][2][tile]
@@ -113,13 +117,17 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     constexpr int XR = ROWS + 1;                             // odd: conflict-free column-major image
     constexpr int NX = (ROWS * 8 + THREADS - 1) / THREADS;   // float4 of x per thread (9)
     constexpr int XFLOATS = 8 * XR * 4;
-    constexpr int MAXEV = NW == 4 ? 6 : 7;                   // chunk IRs one wave evaluates (its slots + 1)
+    constexpr int MAXEV = HONLY ? FZ_HO_MAXEV : (NW == 4 ? 6 : 7);   // chunk IRs one wave evaluates (its slots + 1; HONLY: its share)
+    constexpr int SLOTF = HONLY ? HO_SLOT : HD_SLOT;         // floats per LDS row of taps
+    constexpr int PL4 = 2 * BAS_PLANS_WORDS / 4;             // float4 per chunk IR's pair of plans (18)
+    constexpr int NPV = (MAXEV * PL4 + 63) / 64;             // 16-byte plan pieces per lane
     static_assert(XR % 2 == 1, "x image rows must be odd");
     static_assert(NW != 1 || MAXEV * 2 * BAS_PLANS_WORDS <= HD_SLOT, "NW = 1: the plans must fit the last chunk slot");
+    static_assert(!HONLY || NW == 4, "h-only rows: four-wave workgroups only");
     extern __shared__ f32x4 lds4[];
     f32x4 *xs4 = lds4;                                       // [8][XR] float4
     float *hd = reinterpret_cast<float *>(lds4) + XFLOATS;   // [nslots][HD_SLOT]: (h0_L, h0_R, d_L, d_R) per tap
-    constexpr int PL4 = 2 * BAS_PLANS_WORDS / 4;             // float4 per chunk IR's pair of plans (18)
+                                                             // (HONLY: [nslots + 1][HO_SLOT]: (h_L, h_R) per tap)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -218,9 +226,11 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     int seg0 = 0, Lseg = 0, halo = 0, nrows = 0, c0 = 0, mo0 = 0;
     long xbase = 0;
     // this wave's share of the chunk slots: [slot_a, slot_b), evaluating chunk IRs slot_a .. slot_b
+    // (HONLY: rows [slot_a, slot_b) of the nslots + 1 rows, one chunk IR each)
+    const int nrows_h = A.nslots + (HONLY ? 1 : 0);
     const int slot_a = wv * A.spw;
-    const int slot_b = slot_a + A.spw < A.nslots ? slot_a + A.spw : A.nslots;
-    const int n_ev = slot_a < A.nslots ? slot_b - slot_a + 1 : 0;       // chunk IRs this wave evaluates per pass
+    const int slot_b = slot_a + A.spw < nrows_h ? slot_a + A.spw : nrows_h;
+    const int n_ev = slot_a < nrows_h ? slot_b - slot_a + (HONLY ? 0 : 1) : 0;   // chunk IRs this wave evaluates per pass
 
 #if FZ_START_DELAY
     // The two workgroups of a CU alternate between a latency-bound staging phase and a VALU-bound FIR phase.
@@ -258,14 +268,14 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         __builtin_amdgcn_s_setprio(FZ_STAGE_PRIO);           // staging is latency bound: its few instructions go first
 #endif
         // ---- global -> registers: this wave's read plans (chunk IRs slot_a .. slot_b, both ears) and the x window
-        f32x4 pv[2];
+        f32x4 pv[NPV];
         {
             const f32x4 *pl_src = reinterpret_cast<const f32x4 *>(plans) + (long)s * (A.n_chunks + 1) * PL4;
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < NPV; ++r) {
                 int p = lane + 64 * r;                       // 16-byte piece of the wave's n_ev * 18
                 p = p < n_ev * PL4 ? p : 0;
-                const int i = (p * 3641) >> 16;              // p / 18 for p < 128
+                const int i = (p * 3641) >> 16;              // p / 18 for p < 1000
                 const int c = clampi(c0 + slot_a + i, 0, A.n_chunks);
 #if FZ_NT_LOADS
                 pv[r] = __builtin_nontemporal_load(pl_src + (long)c * PL4 + (p - i * PL4));
@@ -298,9 +308,9 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         // ---- registers -> LDS: plans into this wave's own region, the x window as a column-major image
         // (NW = 1: the plans overlay the last chunk slot, which this wave writes only after its last plan read)
         f32x4 *plw = NW == 1 ? reinterpret_cast<f32x4 *>(hd + (A.nslots - 1) * HD_SLOT)
-                             : reinterpret_cast<f32x4 *>(hd + A.nslots * HD_SLOT) + wv * (MAXEV * PL4);
+                             : reinterpret_cast<f32x4 *>(hd + ((nrows_h * SLOTF + 3) & ~3)) + wv * (MAXEV * PL4);
 #pragma unroll
-        for (int r = 0; r < 2; ++r)
+        for (int r = 0; r < NPV; ++r)
             if (lane + 64 * r < n_ev * PL4) plw[lane + 64 * r] = pv[r];
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
@@ -328,6 +338,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             const f32x4 *pl = plw + half * (BAS_PLANS_WORDS / 4);
             const int tq = 4 * (lane & 31) + (lane < 32 ? 2 : 0);          // first of the two taps this lane stores
             f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tq;
+            f32x2 *dst_h = reinterpret_cast<f32x2 *>(hd) + slot_a * (HO_SLOT / 2) + tq;    // HONLY rows: 8 bytes per tap
             FzHalf ha, hb;
             f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
             const f32x4 *pl_last = pl + (n_ev > 0 ? n_ev - 1 : 0) * PL4;
@@ -340,16 +351,26 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                 f32x4 h = fz_finish<0>(pl, ha, f32x4{0.f, 0.f, 0.f, 0.f});
                 fz_issue<0>(tab, pl_next, m4, L4, ha);
                 h = fz_finish<1>(pl, hb, h) * live;
-                // slot i - 1 = (IR i-1, IR i - IR i-1); iteration 0 writes scrap into slot 0, iteration 1 replaces it
-                f32x2 h0a, h0b, da, db;
-                fz_pair_ears(prev, h0a, h0b);
-                fz_pair_ears(h - prev, da, db);
-                if (tq < Lseg) {
-                    dst[0] = f32x4{h0a.x, h0a.y, da.x, da.y};
-                    dst[1] = f32x4{h0b.x, h0b.y, db.x, db.y};
+                if constexpr (HONLY) {                       // row i of this wave = (left, right) of its IR i
+                    f32x2 ta, tb;
+                    fz_pair_ears(h, ta, tb);
+                    if (tq < Lseg) {
+                        dst_h[0] = ta;
+                        dst_h[1] = tb;
+                    }
+                    dst_h += HO_SLOT / 2;
+                } else {
+                    // slot i - 1 = (IR i-1, IR i - IR i-1); iteration 0 writes scrap into slot 0, iteration 1 replaces it
+                    f32x2 h0a, h0b, da, db;
+                    fz_pair_ears(prev, h0a, h0b);
+                    fz_pair_ears(h - prev, da, db);
+                    if (tq < Lseg) {
+                        dst[0] = f32x4{h0a.x, h0a.y, da.x, da.y};
+                        dst[1] = f32x4{h0b.x, h0b.y, db.x, db.y};
+                    }
+                    if (i > 0) dst += HD_SLOT / 4;
+                    prev = h;
                 }
-                if (i > 0) dst += HD_SLOT / 4;
-                prev = h;
                 pl = pl_next;
             }
         }
@@ -394,9 +415,9 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             float xr[32];
             fz_load_xrow<XR>(xr, xrow);
 #if FZ_FFA
-            ffa_row_step_x(fa, fb, fp, xr, hd + sl * HD_SLOT + (32 * rp - 32) * 4, al[0], mk);
+            ffa_row_step_x<HONLY>(fa, fb, fp, xr, hd + sl * SLOTF + (32 * rp - 32) * (HONLY ? 2 : 4), al[0], mk);
 #else
-            hd_row_step_x<1, false>(acc, xr, hd + sl * HD_SLOT + (32 * rp - 32) * 4, al, mk);
+            hd_row_step_x<1, HONLY>(acc, xr, hd + sl * SLOTF + (32 * rp - 32) * (HONLY ? 2 : 4), al, mk);
 #endif
             xrow -= 1;
             m_in -= 32;
@@ -438,7 +459,8 @@ extern "C" int bas_debug_read_fz_stamps(unsigned long long *host, size_t count) 
 // host side
 // ---------------------------------------------------------------------------
 struct FzPlan {
-    int nw;                    // waves per workgroup: 4, 2 or 1 (0: shape not served)
+    int nw;                    // waves per workgroup: 4 or 1 (0: shape not served)
+    int honly;                 // LDS rows hold (h_L, h_R) only (chunk sizes below ~448)
     int tile, nslots, spw;
     long n_tiles, units_total;
     int n_wg, units_per_wg, parts_per_wg;
@@ -497,9 +519,34 @@ static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
 static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
     FzPlan p = {};
     if (n_src <= 0 || T_in <= 0 || K < 32 || K % 32 != 0 || S % 32 != 0 || K % S != 0 || L <= 0) return p;
-    if (fz_slots(4, K) > FZ_MAXSLOTS) return p;              // K >= 448 or so
     const long T_out = T_in + L - 1;
     const int cus = bas_device_cus();
+    if (fz_slots(4, K) > FZ_MAXSLOTS) {                      // K < 448 or so: h-only rows, four-wave workgroups, two per CU
+        const long n_tiles = (T_out + 8191) / 8192;
+        const int rows_h = fz_slots_exact(4, K, (L + 7) & ~7, n_tiles) + 1;
+        const int spw = (rows_h + 3) / 4;
+        const int xrows = 8192 / 32 + HD_HALO;
+        const size_t lds = (size_t)(8 * (xrows + 1) * 4 + ((rows_h * HO_SLOT + 3) & ~3) + 4 * FZ_HO_MAXEV * 2 * BAS_PLANS_WORDS) * sizeof(float);
+        const long units = n_tiles * n_src;
+        if (spw > FZ_HO_MAXEV || 2 * lds > 160 * 1024 || units < 2L * cus) return p;   // (few sources: the stored-IR path)
+#ifdef BAS_DIAG
+        if (getenv("BAS_FZ_NW") && atoi(getenv("BAS_FZ_NW")) != 4) return p;
+#endif
+        p.nw = 4;
+        p.honly = 1;
+        p.tile = 8192;
+        p.nslots = rows_h - 1;
+        p.spw = spw;
+        p.n_tiles = n_tiles;
+        p.units_total = units;
+        const long wg = 2L * cus;
+        p.units_per_wg = (int)((units + wg - 1) / wg);
+        p.n_wg = (int)((units + p.units_per_wg - 1) / p.units_per_wg);
+        p.parts_per_wg = (p.units_per_wg + n_src - 2) / n_src + 1;
+        p.lds_bytes = lds;
+        p.slab_bytes = (size_t)p.n_wg * p.parts_per_wg * 2 * p.tile * sizeof(float);
+        return p;
+    }
     // largest tile that still gives every workgroup slot of the chip a unit; scenes with few sources (one source
     // x 10 s is 54 tiles of 8192) take smaller tiles and with them more, narrower workgroups
     const int cand[2] = {4, 1};                              // (a tile of 4096 never wins: same number of busy waves as 2048)
@@ -518,7 +565,7 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         if (spw + 1 > maxev) continue;
         const int rows = 2048 * nw / 32 + HD_HALO;
         // (one-wave workgroups keep their plans in the LAST slot's space: that slot is written after the last plan read)
-        const size_t lds = (size_t)(8 * (rows + 1) * 4 + nslots * HD_SLOT + (nw == 1 ? 0 : nw * maxev * 2 * BAS_PLANS_WORDS)) * sizeof(float);
+        const size_t lds = (size_t)(8 * (rows + 1) * 4 + ((nslots * HD_SLOT + 3) & ~3) + (nw == 1 ? 0 : nw * maxev * 2 * BAS_PLANS_WORDS)) * sizeof(float);
         long wg_per_cu = (long)(160 * 1024 / lds);
         const long by_waves = 8 / nw;                        // two waves per SIMD (register budget of the row step)
         if (wg_per_cu > by_waves) wg_per_cu = by_waves;
@@ -619,7 +666,7 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
     A.T_out = T_out;
     float *slab = reinterpret_cast<float *>(ws);
     typedef void (*fz_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
-    const fz_fn fn = p.nw == 4 ? bas_render_fz_kernel<4> : bas_render_fz_kernel<1>;
+    const fz_fn fn = p.honly ? bas_render_fz_kernel<4, true> : p.nw == 4 ? bas_render_fz_kernel<4, false> : bas_render_fz_kernel<1, false>;
     hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
     hipEvent_t eb = reinterpret_cast<hipEvent_t>(ev_begin), ee = reinterpret_cast<hipEvent_t>(ev_end);

@@ -152,15 +152,16 @@ int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, i
 /* ---- a6 + a7 fused: chunk IRs evaluated inside the FIR kernel ------------------
  * bas_interp2d_plan_f32 runs only the per-(query, ear) plan step of bas_interp2d_f32
  * (delays, shift splits, the 16 folded blend weights; apply_hrtf.py:219-279) and
- * leaves n*2 read plans of 160 bytes in `plans` (bas_interp2d_workspace_bytes(n) bytes,
+ * leaves n*2 read plans of 144 bytes in `plans` (bas_interp2d_workspace_bytes(n) bytes,
  * 16-byte aligned; query order [n_src][T_in/K + 1]; needs U >= 4).
  * bas_render_mix_fused_f32 is bas_render_mix_f32 with H replaced by (packed table, plans):
- * every workgroup evaluates the chunk IRs it needs while staging (plans read through the
- * scalar cache, table samples by buffer loads), so the [n][2][L] IR array never exists in
- * HBM.  Served for chunk sizes K >= 448 or so (K % 32 == 0) with subchunks that are
- * multiples of 32: check bas_render_fused_supported (1 = yes) and otherwise use
- * bas_interp2d_f32 + bas_render_mix_f32.  Scenes with few sources get smaller tiles
- * (4096 or 2048 outputs) and more workgroups.  ndir = directions in the table (187).
+ * every workgroup evaluates the chunk IRs it needs while staging (plans staged in LDS,
+ * table samples by buffer loads), so the [n][2][L] IR array never exists in HBM.
+ * Served for chunk sizes K >= 448 or so (K % 32 == 0) with subchunks that are multiples
+ * of 32, and for K >= 256 when the scene has at least two workgroups' worth of
+ * (8192-output tile, source) units per CU: check bas_render_fused_supported (1 = yes) and
+ * otherwise use bas_interp2d_f32 + bas_render_mix_f32.  Scenes with few sources get
+ * smaller tiles (2048 outputs) and more workgroups.  ndir = directions in the table (187).
  * ws / ws_bytes: scratch of bas_render_fused_workspace_bytes(...) bytes, 16-byte aligned.
  * x must be 16-byte aligned with x_stride % 4 == 0 (BAS_E_ALIGN otherwise).
  * ev_begin/ev_end: optional hipEvent_t pair recorded around the FIR kernel (may be NULL). */

@@ -319,7 +319,10 @@ def test_kernel_selection():
     assert lib.bas_render_kernel_name(256, 441000, 30, 10, 128) == b"bas_render_generic_kernel"    # K < 32
     assert lib.bas_render_kernel_name(256, 441090, 490, 49, 128) == b"bas_render_hd_kernel"        # any chunk size
     assert lib.bas_render_fused_supported(256, 441000, 1000, 100, 128) == 0
-    assert lib.bas_render_fused_supported(256, 441344, 256, 32, 128) == 0                          # fused: K >= 448 only
+    assert lib.bas_render_fused_supported(256, 441344, 256, 32, 128) == 1                          # fused with h-only LDS rows
+    assert lib.bas_render_fused_supported(256, 441344, 416, 32, 128) == 1
+    assert lib.bas_render_fused_supported(256, 441344, 224, 32, 128) == 0                          # fused: K >= 256 only
+    assert lib.bas_render_fused_supported(4, 441344, 256, 32, 128) == 0                            # and enough (tile, source) units
     assert lib.bas_render_kernel_name(256, 441344, 512, 16, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 512, 8, 128) == b"bas_render_hd_kernel"
     assert lib.bas_render_kernel_name(256, 441344, 464, 16, 128) == b"bas_render_hd_kernel"       # K % 32 != 0: multi-part rows

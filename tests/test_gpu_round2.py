@@ -407,7 +407,7 @@ def test_fused_path_random_shapes():
                        text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
-    assert last.startswith("worst") and "tile8192" in last and "tile2048" in last, last
+    assert last.startswith("worst") and "tile8192" in last and "tile2048" in last and "h-only" in last, last
 
 
 @pytest.mark.parametrize("k,s,l", [(512, 32, 128), (512, 32, 100), (256, 32, 128), (1024, 64, 128)])
@@ -432,3 +432,33 @@ def test_fast_fir_rounding_margin(tables, k, s, l):
         got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=fused).cpu().numpy()
         assert got.shape == want.shape
         assert rel_err(got, want) <= 2e-6, (fused, rel_err(got, want))
+
+
+@pytest.mark.parametrize("k,s,l", [(256, 32, 128), (320, 64, 100), (384, 128, 128), (416, 32, 200)])
+def test_fused_small_chunks_h_only_rows(tables, k, s, l):
+    """Chunk sizes 256 .. 447 with enough (tile, source) units run the fused kernel with h-only LDS rows
+    (bas_render_fz_kernel<4, true>): against the oracle and against the stored-IR path."""
+    rng = np.random.default_rng(k * 7 + s + l)
+    h = tables["adversarial"].truncated(l)
+    d = _device_table(h)
+    n_src, n = 36, 130000
+    in_length, _ = orc.render_lengths(n, k, l)
+    assert bas._hip.lib().bas_render_fused_supported(n_src, in_length, k, s, l) == 1
+    assert bas._hip.lib().bas_render_fused_supported(2, in_length, k, s, l) == 0          # few sources: stored-IR path
+    sigs = np.stack([bas.synth.integer_noise(int(rng.integers(1e6)), n, 0.5 / n_src) for _ in range(n_src)])
+    t = np.arange(0, in_length + 1, k, dtype=np.float64)
+    elev = rng.uniform(-1.0, 1.7, size=(n_src, t.size))
+    azim = rng.uniform(-7, 7, size=(n_src, t.size))
+    fz = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=True).cpu().numpy()
+    st = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=False).cpu().numpy()
+    assert rel_err(fz, st) <= 2e-6
+    # oracle on three sources of the scene (the whole scene would take minutes on the CPU)
+    sub = [0, 17, 35]
+    irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(t.size)]) for i in sub]
+    want = orc.render_mix(sigs[sub], k, s, irs, normalize=False)
+    got = bas.render_sources(sigs[sub], k, s, elev[sub], azim[sub], d, normalize="none").cpu().numpy()
+    assert rel_err(got, want) <= REL
+    # the fused render of the whole scene is linear in its sources: remove the other 33 through the stored-IR path
+    rest = [i for i in range(n_src) if i not in sub]
+    others = bas.render_sources(sigs[rest], k, s, elev[rest], azim[rest], d, normalize="none", fused=False).cpu().numpy()
+    assert np.abs((fz - others) - want).max() <= 4e-6 * np.abs(fz).max()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised check of the fused path (bas_render_fz_kernel: tiles of 8192 and 2048, direct output, slab reduce, wide
-reduce, several tap segments) against the oracle on the adversarial table: random IR lengths, chunk / subchunk sizes,
+"""Randomised check of the fused path (bas_render_fz_kernel: tiles of 8192 and 2048, h-only rows for chunk sizes below
+448, direct output, slab reduce, wide reduce, several tap segments) against the oracle on the adversarial table: random IR lengths, chunk / subchunk sizes,
 source counts and signal lengths, random (not smooth) trajectories.   python tools/stress_fused.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
@@ -17,8 +17,13 @@ t_start = time.time()
 for case in range(cases):
     l = int(rng.choice([1, 7, 64, 100, 128, 128, 128, 129, 200, 300]))
     s = 32 * int(rng.integers(1, 9))
-    k = s * int(rng.integers(max(1, -(-448 // s)), max(2, 4096 // s) + 1))
-    big = rng.random() < 0.35                                 # enough (tile, source) units for tiles of 8192
+    small_k = rng.random() < 0.3                              # chunk sizes 256 .. 447: the fused kernel's h-only rows
+    if small_k:
+        s = 32 * int(rng.integers(1, 5))
+        k = s * int(rng.integers(-(-256 // s), max(-(-256 // s) + 1, 447 // s + 1)))
+    else:
+        k = s * int(rng.integers(max(1, -(-448 // s)), max(2, 4096 // s) + 1))
+    big = small_k or rng.random() < 0.35                      # enough (tile, source) units for tiles of 8192
     n_src = int(rng.integers(24, 48)) if big else int(rng.integers(1, 9))
     n = int(rng.integers(100000, 160000)) if big else int(rng.integers(1, 40000))
     h = full.truncated(l)
@@ -35,7 +40,7 @@ for case in range(cases):
     err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
     worst = max(worst, err)
     units4 = -(-(in_length + l - 1) // 8192) * n_src
-    kind = "tile8192" if units4 >= 512 else "tile2048"
+    kind = ("h-only" if k < 448 else "tile8192") if units4 >= 512 else "tile2048"
     seen[kind] = seen.get(kind, 0) + 1
     print(f"case {case:3d} L={l:4d} K={k:5d} S={s:4d} n_src={n_src:3d} n={n:6d} {kind} rel err {err:.2e}", flush=True)
     assert got.shape == want.shape and err < 1e-5, "PARITY FAILURE"
