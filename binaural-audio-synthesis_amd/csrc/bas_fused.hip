@@ -4,7 +4,8 @@
 //
 // Work split and FIR: as bas_render_hd_kernel (bas_render.hip) - a workgroup of NW waves owns a tile of
 // 2048 NW outputs and walks over (tile, source) units with the mix in registers; lane = one row of 32 outputs;
-// row step = 32 x 32 Toeplitz block of packed FMAs on an x row and 64 (h0, d) taps from LDS (bas_fir.h).
+// row step = 32 x 32 Toeplitz block of packed FMAs on an x row and 64 (h0, d) taps from LDS, evaluated as a
+// 2-parallel fast FIR (three half-rate products instead of four: bas_fir.h).
 //
 // What is different here
 //   * chunk IRs come from read plans with precomputed byte offsets (EarPlanS, bas_plan.h).  Wave w evaluates
@@ -20,6 +21,8 @@
 //     when the tile changes: no 64-bit divisions per pass; the per-lane chunk slot comes from a float estimate.
 //   * NW = 4 or 1 waves per workgroup (tile 8192 / 2048): scenes with few sources (BASELINE configs 2 and 3:
 //     ONE source) get four times the workgroups out of the same signal.
+//   * chunk sizes 256 .. 447 (template parameter HONLY): LDS rows of (h_L, h_R) only, d formed in the row step,
+//     the waves evaluate disjoint sets of chunk IRs.
 // No MFMA: this is a 1-D FIR (BASELINE.json north_star).
 #include "bas_internal.h"
 #include "bas_plan.h"
