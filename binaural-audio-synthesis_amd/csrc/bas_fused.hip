@@ -197,8 +197,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                 }
             }
             if (peak_bits) {
-                for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-                if (lane == 0) atomicMax(peak_bits, __float_as_uint(lmax));
+                bas_wave_peak_max(lmax, peak_bits);
             }
             FZ_ACC_CLEAR();
             return;

@@ -67,3 +67,28 @@ __device__ __forceinline__ int bas_submod(int a, int b, int M) {
     const int c = a - b;
     return c < 0 ? c + M : c;
 }
+
+// max|.| of a wave into *peak_bits (float bits of a non-negative value: unsigned order = float order).
+// Atomics on ONE address serialise at ~12 ns each whatever the CU they come from - 1 724 waves of the slab reduce
+// spent 21 of its 25 us there - so a wave first reads the published peak (coherently: past the per-XCD L2) and only
+// sends its atomic when it would raise it; the value only grows within a launch, a stale read costs an atomic, no more.
+__device__ __forceinline__ void bas_wave_peak_max(float lmax, unsigned int *peak_bits) {
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned int mine = __float_as_uint(lmax);
+        if (mine > __hip_atomic_load(peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(peak_bits, mine);
+    }
+}
+
+// The same for a whole workgroup of 256 threads (every thread must call it): the waves meet in LDS first, one
+// thread reads the published peak and sends at most one atomic per workgroup.
+__device__ __forceinline__ void bas_block_peak_max(float lmax, unsigned int *peak_bits) {
+    __shared__ float wave_max[4];
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if ((threadIdx.x & 63) == 0) wave_max[(threadIdx.x >> 6) & 3] = lmax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int mine = __float_as_uint(fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3])));
+        if (mine > __hip_atomic_load(peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(peak_bits, mine);
+    }
+}

@@ -782,8 +782,7 @@ __global__ __launch_bounds__(256) void bas_render_generic_kernel(const float *__
         lmax = fmaxf(lmax, fmaxf(fabsf(al_l), fabsf(al_r)));
     }
     if (peak_bits) {
-        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(peak_bits, __float_as_uint(lmax));
+        bas_block_peak_max(lmax, peak_bits);
     }
 }
 
@@ -829,8 +828,7 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__res
         }
     }
     if (peak_bits) {
-        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(peak_bits, __float_as_uint(lmax));
+        bas_block_peak_max(lmax, peak_bits);
     }
 }
 
@@ -885,8 +883,7 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_wide_kernel(const float *
         }
     }
     if (peak_bits) {
-        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        if ((threadIdx.x & 63) == 0 && lmax > 0.f) atomicMax(peak_bits, __float_as_uint(lmax));
+        bas_block_peak_max(lmax, peak_bits);
     }
 }
 
@@ -898,8 +895,7 @@ __global__ __launch_bounds__(256) void bas_absmax_kernel(const float *__restrict
     float lmax = 0.f;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L)
         lmax = fmaxf(lmax, fabsf(y[i]));
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(peak_bits, __float_as_uint(lmax));
+    bas_block_peak_max(lmax, peak_bits);
 }
 
 __global__ __launch_bounds__(256) void bas_scale_kernel(float *__restrict__ y, long n,
@@ -922,8 +918,7 @@ __global__ __launch_bounds__(256) void bas_mix_partials_kernel(const float *__re
         lmax = fmaxf(lmax, fabsf(v));
     }
     if (peak_bits) {
-        for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
-        if ((threadIdx.x & 63) == 0) atomicMax(peak_bits, __float_as_uint(lmax));
+        bas_block_peak_max(lmax, peak_bits);
     }
 }
 
