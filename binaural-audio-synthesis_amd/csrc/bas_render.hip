@@ -1229,7 +1229,7 @@ extern "C" int bas_scale_by_peak_f32(float *y, long n, const float *peak, bas_st
     BAS_REQUIRE(peak && (y || n == 0), BAS_E_NULL, "bas_scale_by_peak_f32: null pointer");
     BAS_REQUIRE(n >= 0, BAS_E_SHAPE, "bas_scale_by_peak_f32: n < 0");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(bas_scale_kernel, dim3(bas_grid_for(n, 2048)), dim3(256), 0, bas_stream(stream), y, n, peak);
+    hipLaunchKernelGGL(bas_scale_kernel, dim3(bas_grid_for(n, 512)), dim3(256), 0, bas_stream(stream), y, n, peak);
     return bas_check_launch("bas_scale_by_peak_f32");
 }
 
