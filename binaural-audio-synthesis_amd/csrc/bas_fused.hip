@@ -32,9 +32,15 @@
 #ifdef BAS_STAMPS
 // Diagnostic build only (make stamps): per-wave totals of the pass phases in 10 ns ticks (s_memrealtime).
 __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
+#ifdef BAS_LIFETIME_ONLY      // only the wave's first and last instruction are stamped: no waits added inside a pass
+#define FZ_STAMP(var)
+#define FZ_STAMP_NW(var)
+#define FZ_ADD(slot, a, b)
+#else
 #define FZ_STAMP(var) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long var = __builtin_amdgcn_s_memrealtime()
 #define FZ_STAMP_NW(var) const unsigned long long var = __builtin_amdgcn_s_memrealtime()
 #define FZ_ADD(slot, a, b) st_acc[slot] += (b) - (a)
+#endif
 #else
 #define FZ_STAMP(var)
 #define FZ_STAMP_NW(var)
@@ -394,6 +400,9 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             if ((t & 1u) ^ prio_flip) __builtin_amdgcn_s_setprio(2);
             else __builtin_amdgcn_s_setprio(0);
         }
+#elif defined(FZ_ASYM_PRIO)
+        if (prio_flip) __builtin_amdgcn_s_setprio(0);        // experiment: the first half of the grid always goes first
+        else __builtin_amdgcn_s_setprio(FZ_ASYM_PRIO);
 #elif FZ_STAGE_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -444,7 +453,8 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
 #ifdef BAS_STAMPS
     if (lane == 0 && blockIdx.x < 2048) {
         unsigned long long *d = bas_fz_stamps + (blockIdx.x * 4 + wv) * 8;
-        for (int i = 0; i < 6; ++i) d[i] = st_acc[i];
+        for (int i = 0; i < 5; ++i) d[i] = st_acc[i];
+        d[5] = st_begin;                                     // (absolute: who started when)
         d[6] = __builtin_amdgcn_s_memrealtime() - st_begin;
         d[7] = (unsigned long long)n_pass;
     }
