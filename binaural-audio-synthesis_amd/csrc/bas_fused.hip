@@ -581,6 +581,9 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         long wg_per_cu = (long)(160 * 1024 / lds);
         const long by_waves = 8 / nw;                        // two waves per SIMD (register budget of the row step)
         if (wg_per_cu > by_waves) wg_per_cu = by_waves;
+#ifdef BAS_DIAG
+        if (getenv("BAS_FZ_WG_PER_CU")) wg_per_cu = atoi(getenv("BAS_FZ_WG_PER_CU"));   // diagnostic: a workgroup alone on its CU
+#endif
         if (wg_per_cu < 1) continue;
         const long slots = wg_per_cu * cus;
         const long n_tiles = (T_out + 2048L * nw - 1) / (2048L * nw);
