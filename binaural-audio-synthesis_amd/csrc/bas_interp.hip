@@ -383,7 +383,7 @@ extern "C" size_t bas_interp2d_workspace_bytes(int n) {
 
 extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double *w, int n, int ndir,
                                      int L, int U, void *plans, size_t plans_bytes, bas_stream_t stream) {
-    BAS_REQUIRE(diffs && idx && w, BAS_E_NULL, "bas_interp2d_plan_f32: null pointer");
+    BAS_REQUIRE(diffs && ((idx && w) || n == 0), BAS_E_NULL, "bas_interp2d_plan_f32: null pointer");   // (no queries: idx, w may be null)
     BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
                 "bas_interp2d_plan_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
     BAS_REQUIRE((long)2 * ndir * BAS_PLANE(L) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_plan_f32: table too large");
@@ -404,7 +404,7 @@ extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, co
 extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *idx,
                                 const double *w, int n, int ndir, int L, int U, float *H, void *ws,
                                 size_t ws_bytes, bas_stream_t stream) {
-    BAS_REQUIRE(packed && diffs && idx && w && H, BAS_E_NULL, "bas_interp2d_f32: null pointer");
+    BAS_REQUIRE(packed && diffs && ((idx && w && H) || n == 0), BAS_E_NULL, "bas_interp2d_f32: null pointer");   // (no queries: idx, w, H may be null)
     BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U > 0, BAS_E_SHAPE,
                 "bas_interp2d_f32: need n>=0, ndir>0, L>0, U>0 (n=%d ndir=%d L=%d U=%d)", n, ndir, L, U);
     BAS_REQUIRE((long)2 * ndir * BAS_PLANE(L) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_f32: table too large");

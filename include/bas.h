@@ -164,7 +164,8 @@ int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, i
  * smaller tiles (2048 outputs) and more workgroups.  ndir = directions in the table (187).
  * ws / ws_bytes: scratch of bas_render_fused_workspace_bytes(...) bytes, 16-byte aligned.
  * x must be 16-byte aligned with x_stride % 4 == 0 (BAS_E_ALIGN otherwise).
- * ev_begin/ev_end: optional hipEvent_t pair recorded around the FIR kernel (may be NULL). */
+ * ev_begin/ev_end: optional hipEvent_t pair recorded around the FIR kernel (may be NULL). 
+ * n == 0 (no queries / no sources) is served by every entry point: the per-query arrays may then be NULL. */
 int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double *w, int n,
                           int ndir, int L, int U, void *plans, size_t plans_bytes,
                           bas_stream_t stream);

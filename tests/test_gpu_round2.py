@@ -462,3 +462,30 @@ def test_fused_small_chunks_h_only_rows(tables, k, s, l):
     rest = [i for i in range(n_src) if i not in sub]
     others = bas.render_sources(sigs[rest], k, s, elev[rest], azim[rest], d, normalize="none", fused=False).cpu().numpy()
     assert np.abs((fz - others) - want).max() <= 4e-6 * np.abs(fz).max()
+
+
+def test_edge_shapes_no_sources_and_tiny_signals(tables):
+    """Edges the reference handles by construction (apply_hrtf.py:405-414 pads to whole chunks): no sources at all, one sample,
+    exactly one chunk, one sample more than a chunk - through both render paths."""
+    import torch
+    h = tables["consistent"].truncated(128)
+    d = _device_table(h)
+    k, s, l = 512, 32, 128
+    # no sources: silence of the padded length, peak 0
+    in_length, out_length = orc.render_lengths(1000, k, l)
+    y = bas.render_sources(np.zeros((0, 1000), dtype=np.float32), k, s, np.zeros((0, in_length // k + 1)),
+                           np.zeros((0, in_length // k + 1)), d, normalize="mix")
+    assert tuple(y.shape) == (out_length, 2) or tuple(y.shape) == (2, out_length)
+    assert float(torch.as_tensor(y).abs().max()) == 0.0
+    rng = np.random.default_rng(5)
+    for n in (1, k - 1, k, k + 1):
+        in_length, _ = orc.render_lengths(n, k, l)
+        t = np.arange(0, in_length + 1, k, dtype=np.float64)
+        sigs = rng.standard_normal((2, n)).astype(np.float32)
+        elev = rng.uniform(-0.7, 1.4, size=(2, t.size))
+        azim = rng.uniform(-3, 3, size=(2, t.size))
+        irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(t.size)]) for i in range(2)]
+        want = orc.render_mix(sigs, k, s, irs, normalize=False)
+        for fused in (True, False):
+            got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=fused).cpu().numpy()
+            assert got.shape == want.shape and rel_err(got, want) <= REL, (n, fused)
