@@ -543,9 +543,12 @@ def main():
                          "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes},
             "valu": {"achieved": algo_flops / fir_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": algo_flops / fir_s / 1e12 / FP32_VALU_PEAK_TF,
-                     "note": "the FIR is 128 flop/B: fp32-VALU bound, HBM fraction tops out near 15 %; peak is nominal "
-                             "(2.4 GHz) - a bare v_pk_fma_f32 stream on random operands sustains ~97 TFLOP/s "
-                             "(power-limited clock; profiles/r02_ubench_*.txt, DESIGN.md 4)"},
+                     "executed": algo_flops * (3136 + 384) / (4096 + 256) / fir_s / 1e12,
+                     "note": "the FIR is 128 flop/B: fp32-VALU bound, HBM fraction tops out near 15 %.  achieved = direct-form "
+                             "arithmetic (4 L flop per source sample) per second; the row step is a 2-parallel fast FIR and "
+                             "executes 3/4 of those multiplications plus forming (executed).  peak is nominal (2.4 GHz): a "
+                             "bare v_pk_fma_f32 stream on random operands sustains ~122 TFLOP/s (power-limited clock; "
+                             "profiles/r02_ubench_fir_pattern.txt, DESIGN.md 4.1)"},
         }
         if extra:
             out["extra"] = extra
