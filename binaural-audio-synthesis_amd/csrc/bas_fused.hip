@@ -453,8 +453,10 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
 #ifdef BAS_STAMPS
     if (lane == 0 && blockIdx.x < 2048) {
         unsigned long long *d = bas_fz_stamps + (blockIdx.x * 4 + wv) * 8;
-        for (int i = 0; i < 5; ++i) d[i] = st_acc[i];
-        d[5] = st_begin;                                     // (absolute: who started when)
+        for (int i = 0; i < 6; ++i) d[i] = st_acc[i];
+#ifdef BAS_LIFETIME_ONLY
+        d[5] = st_begin;                                     // (absolute: who started when; no phase is stamped in this build)
+#endif
         d[6] = __builtin_amdgcn_s_memrealtime() - st_begin;
         d[7] = (unsigned long long)n_pass;
     }
