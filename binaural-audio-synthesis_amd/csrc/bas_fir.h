@@ -166,3 +166,54 @@ __device__ __forceinline__ void ffa_row_step_x(f32x2 (&fa)[16], f32x2 (&fb)[17],
     FFA_MASKED_OCTET(4) FFA_MASKED_OCTET(5) FFA_MASKED_OCTET(6) FFA_MASKED_OCTET(7)
 #undef FFA_MASKED_OCTET
 }
+
+// The fast form for rows that hold NSUB = 2 subchunks (S = 16): inputs 0-15 of the row meet the taps formed with al[0],
+// inputs 16-31 those formed with al[1]; x_e[q], x_o[q] and their sum all lie in group q / 8.
+template <int I>
+__device__ __forceinline__ void ffa2_octet_fma(f32x2 (&fa)[16], f32x2 (&fb)[17], f32x2 (&fp)[16], const float (&xr)[32],
+                                                const float (&xs)[16], const f32x4 (&hv)[8], const float (&al)[2]) {
+    f32x2 ge[2][4], go[2][4], gs[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            ge[u][jj] = __builtin_elementwise_fma(f32x2{hv[2 * jj].z, hv[2 * jj].w}, f32x2{al[u], al[u]},
+                                                  f32x2{hv[2 * jj].x, hv[2 * jj].y});
+            go[u][jj] = __builtin_elementwise_fma(f32x2{hv[2 * jj + 1].z, hv[2 * jj + 1].w}, f32x2{al[u], al[u]},
+                                                  f32x2{hv[2 * jj + 1].x, hv[2 * jj + 1].y});
+            gs[u][jj] = ge[u][jj] + go[u][jj];
+        }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int dk = 4 * I + jj - 16;
+#pragma unroll
+        for (int p = -1; p < 16; ++p) {
+            const int q = p - dk;
+            if (q >= 0 && q < 16) {
+                const int u = q >> 3;
+                if (p >= 0) {
+                    fma2(fa[p], xr[2 * q], ge[u][jj]);
+                    fma2(fp[p], xs[q], gs[u][jj]);
+                }
+                fma2(fb[p + 1], xr[2 * q + 1], go[u][jj]);
+            }
+        }
+    }
+}
+
+template <bool HONLY = false>
+__device__ __forceinline__ void ffa2_row_step_x(f32x2 (&fa)[16], f32x2 (&fb)[17], f32x2 (&fp)[16], const float (&xr)[32],
+                                                 const float *__restrict__ hdrow, const float (&al)[2], unsigned live_mask) {
+    float xs[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) xs[q] = xr[2 * q] + xr[2 * q + 1];
+    f32x4 hv[8];
+#define FFA2_MASKED_OCTET(I)                           \
+    if (live_mask & (1u << I)) {                       \
+        hd_load_octet<HONLY>(hv, hdrow, I);            \
+        ffa2_octet_fma<I>(fa, fb, fp, xr, xs, hv, al); \
+    }
+    FFA2_MASKED_OCTET(0) FFA2_MASKED_OCTET(1) FFA2_MASKED_OCTET(2) FFA2_MASKED_OCTET(3)
+    FFA2_MASKED_OCTET(4) FFA2_MASKED_OCTET(5) FFA2_MASKED_OCTET(6) FFA2_MASKED_OCTET(7)
+#undef FFA2_MASKED_OCTET
+}

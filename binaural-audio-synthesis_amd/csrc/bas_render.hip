@@ -465,9 +465,10 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
     unsigned long long st_fir = 0;
 #endif
 
-    // one alpha per whole row (NSUB = 1, no multi-part rows): the row step runs as a 2-parallel fast FIR on half-rate partial sums that
-    // are combined into the 32 outputs when the tile is flushed (bas_fir.h); otherwise the direct form on acc
-    constexpr bool FFA = NSUB == 1 && !DUAL;            // (multi-part rows hold too much other state: 200 spilled registers)
+    // one alpha per whole row, or two with (h0, d) slots (NSUB = 2: S = 16; with h-only slots 52 spilled registers make it
+    // slower), no multi-part rows (200 spilled registers): the row step runs as a 2-parallel fast FIR on half-rate partial
+    // sums that are combined into the 32 outputs when the tile is flushed (bas_fir.h); otherwise the direct form on acc
+    constexpr bool FFA = (NSUB == 1 || (NSUB == 2 && !HONLY)) && !DUAL;
     f32x2 acc[32];
     f32x2 fa[16], fb[17], fp[16];
 #pragma unroll
@@ -716,10 +717,14 @@ __global__ __launch_bounds__(HD_THREADS, 2) void bas_render_hd_kernel(RenderArgs
                 float al[NSUB];
                 const float *hdrow;
                 step_setup(rp, al, hdrow);
-                if constexpr (FFA) {
+                if constexpr (FFA && NSUB == 1) {
                     float xr[32];
                     hd_load_xrow(xr, xrow);
                     ffa_row_step_x<HONLY>(fa, fb, fp, xr, hdrow, al[0], mask_of(rp));
+                } else if constexpr (FFA && NSUB == 2) {
+                    float xr[32];
+                    hd_load_xrow(xr, xrow);
+                    ffa2_row_step_x<HONLY>(fa, fb, fp, xr, hdrow, al, mask_of(rp));
                 } else {
                     hd_row_step_masked<NSUB, HONLY>(acc, xrow, hdrow, al, mask_of(rp));
                 }
