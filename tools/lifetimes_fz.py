@@ -36,3 +36,8 @@ h = n_wg // 2
 print(f"{os.path.basename(path)}: {n_wg} workgroups, {a[:, 0, 7].mean():.1f} passes each, kernel {end.max():.1f} us")
 for name, sl in (("first half of the grid", slice(0, h)), ("second half", slice(h, n_wg))):
     print(f"  {name:24s} start {begin[sl].mean():7.1f} us (max {begin[sl].max():7.1f})   end mean {end[sl].mean():7.1f}  p10 {np.percentile(end[sl], 10):7.1f}  p90 {np.percentile(end[sl], 90):7.1f}  max {end[sl].max():7.1f}")
+# end time by XCD (workgroup b runs on XCD b % 8 under round-robin placement) and by position in the grid
+print("  end time by b % 8 :", " ".join(f"{end[i::8].mean():6.1f}" for i in range(8)))
+print("  end time by b // 64:", " ".join(f"{end[i * 64:(i + 1) * 64].mean():6.1f}" for i in range(n_wg // 64)))
+first_src = np.arange(n_wg) * 27 % 256
+print("  corr(end, first source of the share) = %.2f" % np.corrcoef(end, first_src)[0, 1])
