@@ -184,3 +184,44 @@ def test_legacy_index_split_matches_the_oracle():
     for ci in (73.0, 73.25, 95.999, 96.0, 96.5, 96.999999, 0.0, 0.75, 185.2, 120.000001):
         assert apply_hrtf.ring_easy_params(ci) == orc.ring_easy_params(ci)
     assert apply_hrtf.ring_easy_params(96.5) == (96, 73, 0.5)
+
+
+def test_fast_fir_row_step_index_algebra():
+    """The row step of the FIR kernels (csrc/bas_fir.h: ffa_octet_fma / ffa_combine) restated in numpy with the kernel's
+    own index conventions - octet I holds the full-rate taps 8 I + j - 32 relative to the row distance, half-rate tap
+    dk = 4 I + jj - 16 of g_e (j even) and g_o (j odd), accumulators A[16], B[17] (p = -1 .. 15), P[16] - against the
+    direct 32 x 32 Toeplitz block it replaces, for every row distance of a 128-tap IR."""
+    rng = np.random.default_rng(11)
+    L = 128
+    g = rng.standard_normal(L)
+    for rp in range(5):                                          # input row rp rows above the output row
+        x = rng.standard_normal(32)
+        # direct: y[o] += g[32 rp + o - a] x[a]
+        want = np.zeros(32)
+        for o in range(32):
+            for a in range(32):
+                t = 32 * rp + o - a
+                if 0 <= t < L:
+                    want[o] += g[t] * x[a]
+        fa, fb, fp = np.zeros(16), np.zeros(17), np.zeros(16)
+        xs = x[0::2] + x[1::2]
+        for I in range(8):
+            t0 = 32 * rp - 32 + 8 * I
+            if not (0 <= t0 < L):                                # the kernel's live mask
+                continue
+            taps = g[t0:t0 + 8]
+            ge, go = taps[0::2], taps[1::2]
+            gs = ge + go
+            for jj in range(4):
+                dk = 4 * I + jj - 16
+                for p in range(-1, 16):
+                    q = p - dk
+                    if 0 <= q < 16:
+                        if p >= 0:
+                            fa[p] += ge[jj] * x[2 * q]
+                            fp[p] += gs[jj] * xs[q]
+                        fb[p + 1] += go[jj] * x[2 * q + 1]
+        got = np.empty(32)
+        got[0::2] = fa + fb[:16]                                 # y[2p] = A[p] + B[p-1]
+        got[1::2] = (fp - fa) - fb[1:]                           # y[2p+1] = P[p] - A[p] - B[p]
+        assert np.allclose(got, want, rtol=0, atol=1e-12), rp
