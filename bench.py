@@ -72,7 +72,23 @@ def parse():
     ap.add_argument("--block", type=int, default=262144, help="stream mode: input samples per block")
     ap.add_argument("--regen", action="store_true", help="stream mode: draw a fresh random block inside every timed step")
     ap.add_argument("--cpu-sources-per-core", type=int, default=16)
-    return ap.parse_args()
+    ap.add_argument("--lib", default=None, help="another build of the ABI to route every call through (diagnostic / stamps "
+                                                "builds of binaural-audio-synthesis_amd/csrc; profiling tools)")
+    ap.add_argument("--unfused", action="store_true", help="ablation: chunk IRs through HBM (bas_interp2d_f32 + bas_render_mix_f32)")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the render step (a3 -> plans -> FIR -> reduce [-> peak rule]) as ONE captured hipGraph. "
+                         "auto: on whenever the step ends in a collective (N > 1 or --force-pg), where a rank's share is "
+                         "short and launch gaps count; off at N = 1, where the FIR kernel is timed with HIP events inside "
+                         "the timed steps (events cannot be read back from a graph replay)")
+    ap.add_argument("--force-pg", action="store_true",
+                    help="with --gpus 1: still create a real RCCL communicator (backend nccl, world_size 1) and run the "
+                         "N > 1 code path - async gather to rank 0, fixed-order sum, overlapped steps, device-side "
+                         "all_reduce of the settle loop.  Also switched on by BAS_BENCH_FORCE_PG=1")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the oracle comparison of the timed path's output")
+    args = ap.parse_args()
+    if os.environ.get("BAS_BENCH_FORCE_PG") == "1":
+        args.force_pg = True
+    return args
 
 
 # ---------------------------------------------------------------------------
@@ -168,24 +184,37 @@ class HipEvents:
 
 
 def stream_mode(args):
-    """BASELINE config 5 (1024 sources, 48 kHz, hours of audio) in miniature: `steps` blocks of `block`
-    samples through StreamRenderer; nothing but one block of inputs, chunk IRs and outputs is ever resident,
-    and the trajectory -> parameter step runs on the device.  With --gpus N (torch.distributed.run) the
-    1024 sources are sharded over the ranks and every block ends in one gather of the partial stereo block
-    (distributed.ShardedStreamRenderer).  One JSON line, not the contract's metric."""
+    """BASELINE config 5 (1024 sources, 48 kHz, hours of audio): `steps` blocks of `block` samples through
+    StreamRenderer; nothing but one block of inputs, chunk IRs and outputs is ever resident, and the
+    trajectory -> parameter step runs on the device.  `--steps 659` is the whole hour at 48 kHz.  With --gpus N
+    (torch.distributed.run) the sources are sharded over the ranks and every block ends in one gather of the
+    partial stereo block (distributed.ShardedStreamRenderer); --force-pg runs that path on one rank with a real RCCL
+    communicator.  One JSON line, not the contract's metric."""
     import math
     import torch
     import torch.distributed as dist
     import binaural_audio_synthesis_amd as bas
+    from binaural_audio_synthesis_amd import _hip
+    if args.lib:
+        _hip.set_library(os.path.abspath(args.lib))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if os.environ.get("BAS_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    collective = world > 1 or args.force_pg
     if world > 1:
         backend = os.environ.get("BAS_BENCH_BACKEND", "nccl")
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+    elif args.force_pg:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)
     n_total, k, s, l, fs, B = args.sources, args.chunk, args.subchunk, args.taps, args.fs, args.block
     host = bas.synth.make_table("consistent", 0).truncated(l)
     tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left, host.irs_right,
@@ -196,12 +225,13 @@ def stream_mode(args):
     phase = 2 * math.pi * src / n_total
     period = (2.0 + (src % 256) / 64.0) * fs
     gen = torch.Generator(device=dev).manual_seed(5 + rank)
-    gloo = world > 1 and dist.get_backend() == "gloo"
+    gloo = collective and dist.get_backend() == "gloo"
 
     # the input block lives in the renderer's own input buffer (what a decoder / H2D copy would fill in place):
     # resident in HBM when a timed step starts, as the bench contract asks; --regen draws a fresh block per step
     xin = st.local.input_view(B)
     xin.copy_((torch.rand((n_src, B), generator=gen, device=dev) * 2 - 1) * (1.0 / n_total))
+    st.local.prepare(B)                                     # buffers + hipGraph before the stream starts
 
     def block(i):
         t = (torch.arange(B // k + 1, dtype=torch.float64, device=dev)[None, :] * k + i * B)
@@ -216,33 +246,60 @@ def stream_mode(args):
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if collective:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         y = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if collective:
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         t = torch.tensor([el], dtype=torch.float64, device="cpu" if gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
+    # the FIR kernel alone: a few more blocks as plain launches with HIP events around the kernel (events cannot be
+    # read back from a graph replay), outside the timed region
+    loc = st.local
+    n_ev = 5
+    ev = HipEvents(n_ev)
+    loc.graph_enabled, loc._graph = False, None
+    for j in range(n_ev):
+        loc._events = ev.pairs[j]
+        step(args.warmup + args.steps + j)
+    torch.cuda.synchronize()
+    loc._events = None
+    fir_ms = sum(ev.elapsed_ms(j) for j in range(n_ev)) / n_ev
     audio_s = args.steps * B / fs
     if rank == 0:
+        m_cols = l * host.upsampling
+        algo_bytes = 4 * n_src * B + 8 * B + 4 * (2 * 187 * m_cols + 2 * 187 * 187) + 28 * n_src * (B // k + 1)
+        algo_flops = 4 * l * n_src * (B + loc.halo)
         print(json.dumps({"metric": "streaming render, x real-time", "value": audio_s / el, "unit": "x real-time",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "strong", "dtype": "f32",
                           "data": "synthetic; input block resident in the renderer's input buffer" + (" (redrawn every step, included in time)" if args.regen else "") + ", trajectories computed per block on the device (included in time)",
                           "config": {"workload": f"BASELINE config 5 shape: {n_total} sources @ {fs} Hz streamed in blocks of {B} "
                                                  f"samples, chunk {k}, subchunk {s}, {l} taps; sources sharded over {world} GPU(s), "
-                                                 f"one gather per block", "block": B},
+                                                 f"one gather per block; {args.steps} blocks = {audio_s:.0f} s of audio", "block": B},
                           "source_samples_per_s": n_total * B * args.steps / el,
+                          "ps_per_source_sample": el / (n_total * B * args.steps) * 1e12,
                           "hour_of_audio_seconds": 3600.0 / (audio_s / el), "peak": st.peak,
+                          "collective_path": (f"{dist.get_backend()} world_size={world}" if collective else None),
+                          "roofline": {"bound": "hbm", "bound_actual": "fp32 VALU (see the scene line)",
+                                       "achieved": algo_bytes / (fir_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": algo_bytes / (fir_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                       "kernel": "bas_render_fz_kernel", "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes,
+                                       "note": f"algorithmic bytes of one block on this GPU ({n_src} sources): inputs once, stereo "
+                                               f"block once, table, 28 B per chunk boundary; the kernel also re-reads a "
+                                               f"{loc.halo}-sample halo per source.  kernel_ms: HIP events around the FIR kernel in "
+                                               f"{n_ev} plain-launch blocks behind the timed region (the timed blocks are graph replays)"},
+                          "valu": {"achieved": algo_flops / (fir_ms / 1e3) / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": algo_flops / (fir_ms / 1e3) / 1e12 / FP32_VALU_PEAK_TF},
                           "out_block_shape": list(y.shape)}), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 
@@ -315,8 +372,7 @@ class Scene:
         self.parts = torch.empty((world, 2, t_out), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
         self.y_final = torch.empty((2, t_out), dtype=torch.float32, device=dev)
         self.peak = torch.empty((1,), dtype=torch.float32, device=dev)
-        env_fused = os.environ.get("BAS_BENCH_FUSED")            # ablation: "0" forces interp2d + render_mix
-        self.fused = None if env_fused is None else env_fused == "1"
+        self.fused = False if args.unfused else None             # ablation: --unfused forces interp2d + render_mix
         self.fused_used = bool(lib.bas_render_fused_supported(n_src, in_length, k, s, l)) and self.fused is not False
         self.kernel = "bas_render_fz_kernel" if self.fused_used else lib.bas_render_kernel_name(n_src, in_length, k, s, l).decode()
         self.host_u = host_u
@@ -329,14 +385,53 @@ class Scene:
                                                    ws_plans=self.ws_i, fused=self.fused, params=(self.idx, self.w))[1]
 
 
-def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_events):
+def self_check(sc, y_dev, peak_dev, n_windows=2):
+    """Compare windows of the timed path's own output (device a3 -> plans -> fused FIR -> reduce -> peak rule) with
+    the oracle's float64 definition (oracle.render_window over EVERY source of this GPU) - outside the timed
+    region.  Returns the worst norm-relative error (max|got - want| / max|y|)."""
+    import numpy as np
+    from oracle import bas_oracle as orc
+    a = sc.args
+    k, s, l = a.chunk, a.subchunk, a.taps
+    host_tbl = sc.bas.synth.make_table("consistent", 0).truncated(l)
+    elev, azim = sc.elev.cpu().numpy(), sc.azim.cpu().numpy()
+    scale = float(y_dev.abs().max())
+    peak = float(peak_dev.reshape(-1)[0])                    # max|mix| before the peak rule (apply_hrtf.py:462-464)
+    mid = (sc.t_out // 2 // k) * k                           # a chunk boundary in the middle, and the very beginning
+    windows = [(mid - 16, mid + 16), (l - 8, l + 24)][:n_windows]
+    worst = 0.0
+    for n0, n1 in windows:
+        m0, m1 = max(n0 - l + 1, 0), min(n1, sc.in_length)
+        xw = sc.x[:, m0:m1].double().cpu().numpy()
+        want = np.zeros((2, n1 - n0))
+        for i in range(sc.n_src):
+            cache = {}
+
+            def ir_of(c, i=i, cache=cache):
+                c = min(c, sc.n_q - 1)
+                if c not in cache:
+                    cache[c] = orc.interp2d(host_tbl, elev[i, c], azim[i, c])
+                return cache[c]
+            want += orc.render_window(xw[i], m0, k, s, ir_of, l, n0, n1)
+        if peak > 1.0:
+            want /= peak
+        got = y_dev[:, n0:n1].double().cpu().numpy()
+        worst = max(worst, float(np.abs(got - want).max()) / (scale if scale > 0 else 1.0))
+    return worst
+
+
+def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_events, collective):
     """Warm up, time exactly args.steps steps (barrier + synchronize on both sides, max over ranks) and return
-    (elapsed seconds, scene, FIR kernel milliseconds per launch or None)."""
+    (elapsed seconds, scene, FIR kernel milliseconds per launch or None, overlap flag, extra JSON fields)."""
     import torch
     import torch.distributed as dist
     from binaural_audio_synthesis_amd import _hip
     sc = Scene(args, bas, dev, world, rank, scaling, tbl, host_u)
     t_out = sc.t_out
+    info = {}
+    use_graph = args.graph == "on" or (args.graph == "auto" and collective)
+    # events live inside the timed steps only while those are plain launches; under a graph the FIR kernel is timed
+    # in eager steps of its own right after the timed region (same process, same clocks)
     ev = HipEvents(args.steps) if with_events else None
 
     def mix_on_root(parts_buf):
@@ -345,19 +440,47 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
                   _hip.ptr(sc.peak), stream)
         _hip.call("bas_scale_by_peak_f32", _hip.ptr(sc.y_final), 2 * t_out, _hip.ptr(sc.peak), stream)
 
-    def step_single(i_event=None):
-        pk = sc.render_into(sc.y, None if (ev is None or i_event is None) else ev.pairs[i_event])
-        _hip.call("bas_scale_by_peak_f32", _hip.ptr(sc.y), 2 * t_out, _hip.ptr(pk), _hip.current_stream(dev))
+    def render_single(y_buf, events=None):                  # the whole N = 1 step: render + peak rule
+        pk = sc.last_peak = sc.render_into(y_buf, events)
+        _hip.call("bas_scale_by_peak_f32", _hip.ptr(y_buf), 2 * t_out, _hip.ptr(pk), _hip.current_stream(dev))
 
     # N > 1: the gather of step i travels (RCCL stream, xGMI) while step i+1 renders; y and the root's receive
     # buffer are double-buffered, the root sums step i right after it has launched step i+1's gather.  Every
     # collective is issued by all ranks in step order; drain() inside the timed region completes the last one.
     # BAS_BENCH_SYNC_GATHER=1 restores gather-then-continue.
-    overlap = world > 1 and os.environ.get("BAS_BENCH_SYNC_GATHER", "0") != "1"
+    overlap = collective and os.environ.get("BAS_BENCH_SYNC_GATHER", "0") != "1"
     ys = [sc.y, torch.empty_like(sc.y)] if overlap else [sc.y]
+    if collective and sc.parts is None and rank == 0:
+        sc.parts = torch.empty((world, 2, t_out), dtype=torch.float32, device=dev)
     parts2 = [sc.parts, torch.empty_like(sc.parts)] if (overlap and rank == 0) else [sc.parts]
     inflight = [None, None]
     counter = [0]
+
+    # ---- the render part of a step as ONE hipGraph (per output buffer): a3 -> plans -> FIR -> reduce [-> peak rule]
+    graphs = {}
+
+    def render(b, events=None):
+        """Render this rank's sources into ys[b] (collective path: un-normalised partial mix; N = 1: with the peak
+        rule), replaying the captured graph when there is one and no events are asked for."""
+        if use_graph and events is None and b in graphs:
+            graphs[b].replay()
+        elif collective:
+            sc.render_into(ys[b], events)
+        else:
+            render_single(ys[b], events)
+
+    def capture_graphs():
+        for b in range(len(ys)):
+            render(b)                                         # eager first: code objects, workspaces
+        torch.cuda.synchronize(dev)
+        for b in range(len(ys)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                if collective:
+                    sc.render_into(ys[b], None)
+                else:
+                    render_single(ys[b], None)
+            graphs[b] = g
 
     def launch_gather(b, async_op):
         if backend == "nccl":
@@ -380,8 +503,11 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
             mix_on_root(parts2[b])
         inflight[b] = None
 
+    def step_single(i_event=None):
+        render(0, None if (ev is None or i_event is None) else ev.pairs[i_event])
+
     def step_sync(i_event=None):
-        sc.render_into(ys[0], None if (ev is None or i_event is None) else ev.pairs[i_event])
+        render(0, None if (ev is None or i_event is None) else ev.pairs[i_event])
         inflight[0] = launch_gather(0, False)
         finish_gather(0)
 
@@ -389,7 +515,7 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
         b = counter[0] & 1
         counter[0] += 1
         finish_gather(b)                                  # the collective that read ys[b] two steps ago is done
-        sc.render_into(ys[b], None if (ev is None or i_event is None) else ev.pairs[i_event])
+        render(b, None if (ev is None or i_event is None) else ev.pairs[i_event])
         inflight[b] = launch_gather(b, True)
         if rank == 0:
             finish_gather(b ^ 1)                          # previous step: its gather ran beside this render
@@ -400,15 +526,28 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
             finish_gather(b)                              # older one first
             finish_gather(b ^ 1)
 
-    step = step_single if world == 1 else (step_overlapped if overlap else step_sync)
+    step = step_single if not collective else (step_overlapped if overlap else step_sync)
 
     def fence():
         drain()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # ---- cold figure (N = 1 only): what a single render sees on a GPU that has not been loaded yet
+    if not collective and with_events and args.settle_ms > 0:
+        step()                                               # code objects and workspaces only
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize(dev)
+        info["cold"] = {"ms_per_step": (time.perf_counter() - t0) / 20 * 1e3,
+                        "meaning": "the first 20 steps after one untimed step, before the settle phase: the clock "
+                                   "governor has not settled (profiles/r02_warmup_series.txt)"}
+    if use_graph:
+        capture_graphs()
     if args.settle_ms > 0:                                  # untimed: let the clock governor reach its steady state
         t_end = time.perf_counter() + args.settle_ms / 1e3
         while True:
@@ -417,7 +556,7 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
             torch.cuda.synchronize(dev)
             go_on = torch.tensor([1.0 if time.perf_counter() < t_end else 0.0], dtype=torch.float64,
                                  device="cpu" if backend != "nccl" else dev)
-            if world > 1:                                    # every rank must leave the loop at the same step count
+            if collective:                                   # every rank must leave the loop at the same step count
                 dist.all_reduce(go_on, op=dist.ReduceOp.MIN)
             if float(go_on.item()) == 0.0:
                 break
@@ -426,42 +565,77 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(None if use_graph else i)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if backend != "nccl" else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    if overlap and os.environ.get("BAS_BENCH_CHECK") == "1":   # rehearsal: the pipelined mix equals the synchronous one
+    fir_ms = None
+    if ev is not None:
+        if use_graph:                                        # eager steps with events, right behind the timed region
+            for i in range(args.steps):
+                if collective:
+                    sc.render_into(ys[0], ev.pairs[i])
+                else:
+                    render_single(ys[0], ev.pairs[i])
+            torch.cuda.synchronize(dev)
+        per = [ev.elapsed_ms(i) for i in range(args.steps)]
+        fir_ms = sum(per) / len(per)
+    info["graph"] = ("render step replayed as one hipGraph per step; the FIR kernel was timed with HIP events in "
+                     f"{args.steps} eager steps right behind the timed region") if use_graph else "plain launches"
+    if collective:
+        info["collective_path"] = f"{backend} world_size={world}" + (" (--force-pg: one rank, real communicator)" if world == 1 else "")
+    if collective and os.environ.get("BAS_BENCH_CHECK") == "1":   # rehearsal: the pipelined mix equals the synchronous one
         pipelined = sc.y_final.clone() if rank == 0 else None
         step_sync()
         torch.cuda.synchronize(dev)
         if rank == 0:
             assert torch.equal(pipelined, sc.y_final), "overlapped gather changed the mix"
             print("check: pipelined mix == synchronous mix", file=sys.stderr, flush=True)
-    fir_ms = None
-    if ev is not None:
-        per = [ev.elapsed_ms(i) for i in range(args.steps)]
-        fir_ms = sum(per) / len(per)
-    return elapsed, sc, fir_ms, overlap
+            if world == 1:                                   # one rank: the collective path must reproduce the plain step
+                plain = torch.empty_like(sc.y)
+                render_single(plain)
+                torch.cuda.synchronize(dev)
+                assert torch.equal(plain, sc.y_final), "collective path at world_size 1 differs from the plain N = 1 step"
+                print("check: collective path at world_size 1 == plain step, bit for bit", file=sys.stderr, flush=True)
+    if with_events and rank == 0 and not args.no_self_check and scaling == args.scaling:
+        y_chk = sc.y_final if collective else sc.y
+        if not collective or world == 1:                     # (N > 1: the root's mix holds other ranks' sources too)
+            if not collective:
+                render_single(sc.y)                           # (a fresh eager step: under a graph the peak tensor is the pool's)
+                torch.cuda.synchronize(dev)
+            info["self_check_rel_err"] = self_check(sc, y_chk, sc.peak if collective else sc.last_peak)
+            info["self_check"] = ("2 windows of the timed path's output (all sources of this GPU) against "
+                                  "oracle.render_window, float64; bound 1e-5")
+            assert info["self_check_rel_err"] <= 1e-5, f"self check failed: {info['self_check_rel_err']:.3e}"
+    return elapsed, sc, fir_ms, overlap, info
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # The CPU leg starts worker PROCESSES: it runs first, before this process has made any GPU call (anything
+    # exec-shaped belongs in front of the first HIP call on this pool), and it does not depend on the GPU run.
+    cpu_line = None
+    if args.mode == "scene" and world == 1 and not args.no_cpu_baseline:
+        n_cpu = int(round(args.seconds * FS))
+        cpu_line = cpu_baseline(args, n_cpu, -(-n_cpu // args.chunk) * args.chunk + args.taps - 1)
     if args.mode == "stream":
         return stream_mode(args)
     import torch
     import torch.distributed as dist
     import binaural_audio_synthesis_amd as bas
     from binaural_audio_synthesis_amd import _hip
+    if args.lib:
+        _hip.set_library(os.path.abspath(args.lib))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     # rehearsal knobs (a 1-GPU box; self_launch sets them when devices are missing): BAS_BENCH_ONE_DEVICE=1 puts
     # every rank on cuda:0, BAS_BENCH_BACKEND=gloo stages the gather through host memory.
     rehearsal = os.environ.get("BAS_BENCH_ONE_DEVICE") == "1"
@@ -470,23 +644,34 @@ def main():
     backend = os.environ.get("BAS_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    collective = world > 1 or args.force_pg                  # the step ends in the gather + fixed-order sum
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    elif args.force_pg:                                      # one rank, real RCCL communicator
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = "nccl"
+        dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)
 
     k, s, l = args.chunk, args.subchunk, args.taps
     host = bas.synth.make_table("consistent", 0).truncated(l)
     tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left,
                                  host.irs_right, device=dev)
     scaling = args.scaling                                   # (one GPU: the whole scene either way)
-    elapsed, sc, fir_ms, overlap = run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host.upsampling, True)
+    elapsed, sc, fir_ms, overlap, info = run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host.upsampling,
+                                                   True, collective)
     extra = {}
     if world > 1 and not args.no_extra:
         other = "weak" if scaling == "strong" else "strong"
         del sc.x, sc.parts                                   # free the first scene's big buffers
-        e2, sc2, _, _ = run_scene(args, bas, dev, world, rank, backend, other, tbl, host.upsampling, False)
+        e2, sc2, _, _, _ = run_scene(args, bas, dev, world, rank, backend, other, tbl, host.upsampling, False, collective)
         scenes2 = world if other == "weak" else 1
         extra[other] = {"value": scenes2 * sc2.t_out * args.steps / e2, "unit": "stereo samples/s",
                         "ms_per_step": e2 / args.steps * 1e3, "sources_per_gpu": sc2.n_src,
@@ -507,6 +692,9 @@ def main():
         algo_bytes = 4 * n_src * in_length + 8 * t_out + 4 * (2 * 187 * m_cols + 2 * 187 * 187) + 28 * n_src * n_q
         algo_flops = 4 * l * n_src * in_length            # 2 ears x L FMA per source-sample
         fir_s = fir_ms / 1e3
+        # the 2-parallel fast FIR row step (3/4 of the multiplications) serves subchunks that are multiples of 32,
+        # in the fused kernel and in the stored-IR hd kernel; the other kernels execute the direct form
+        fast_fir = s % 32 == 0 and (sc.fused_used or sc.kernel == "bas_render_hd_kernel")
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "fir_hbm_traffic.json")
         if os.path.exists(tpath):
@@ -536,14 +724,20 @@ def main():
                                       (", travelling beside the next step's render" if overlap else "")},
             "x_realtime": (n / FS) * scenes / (elapsed / args.steps),
             "source_samples_per_s": sc.total_src * in_length * args.steps / elapsed,
-            "roofline": {"bound": "hbm", "achieved": algo_bytes / fir_s / 1e9, "peak": HBM_PEAK_GBS,
+            "multi_gpu_status": "no N > 1 figure of this repository is hardware-measured until the driver's SCALE run: the "
+                                "builder's boxes have one GPU (the RCCL path runs there at world_size 1, --force-pg; two "
+                                "ranks on one device under gloo)",
+            "roofline": {"bound": "hbm", "bound_actual": "fp32 VALU at a power-limited clock (see valu; the HBM "
+                         "fraction of a perfect 128-tap direct FIR tops out near 15 %)", "achieved": algo_bytes / fir_s / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / fir_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_source,
                          "kernel": sc.kernel + (" (chunk IRs evaluated while staging)" if sc.fused_used else ""),
                          "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes},
             "valu": {"achieved": algo_flops / fir_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": algo_flops / fir_s / 1e12 / FP32_VALU_PEAK_TF,
-                     "executed": algo_flops * (3136 + 384) / (4096 + 256) / fir_s / 1e12,
+                     **({"executed": algo_flops * (3136 + 384) / (4096 + 256) / fir_s / 1e12,
+                         "frac_executed": algo_flops * (3136 + 384) / (4096 + 256) / fir_s / 1e12 / FP32_VALU_PEAK_TF}
+                        if fast_fir else {}),
                      "note": "the FIR is 128 flop/B: fp32-VALU bound, HBM fraction tops out near 15 %.  achieved = direct-form "
                              "arithmetic (4 L flop per source sample) per second; the row step is a 2-parallel fast FIR and "
                              "executes 3/4 of those multiplications plus forming (executed).  peak is nominal (2.4 GHz): a "
@@ -555,10 +749,11 @@ def main():
         if rehearsal:
             out["rehearsal"] = f"{world} ranks on ONE device, gather staged through host memory ({backend}): " \
                                "a functional check of the multi-rank path, not a scaling measurement"
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, n, t_out)
+        out.update(info)
+        if cpu_line is not None:
+            out["cpu_baseline"] = cpu_line
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

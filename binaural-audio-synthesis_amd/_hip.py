@@ -8,8 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# BAS_LIB_PATH: load another build of the same ABI instead (profiling tools use the diagnostic build this way)
-LIB_PATH = os.environ.get("BAS_LIB_PATH") or os.path.join(_HERE, "csrc", "libbas_hip.so")
+LIB_PATH = os.path.join(_HERE, "csrc", "libbas_hip.so")   # the shipped build; another build of the same ABI is loaded
+                                                           # explicitly: set_library(path) / use_library(path), never by environment
 
 _c_int, _c_long, _c_size_t, _c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_size_t, ctypes.c_void_p
 
@@ -24,6 +24,8 @@ SIGNATURES = {
                                      _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "bas_traj_params_f64": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
                                      _c_void_p, _c_void_p, _c_void_p]),
+    "bas_traj_params_branch_f64": (_c_int, [_c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p, _c_void_p, _c_void_p,
+                                            _c_void_p, _c_void_p, _c_int, _c_void_p]),
     "bas_interp2d_workspace_bytes": (_c_size_t, [_c_int]),
     "bas_interp2d_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int,
                                   _c_int, _c_void_p, _c_void_p, _c_size_t, _c_void_p]),
@@ -44,10 +46,12 @@ SIGNATURES = {
     "bas_peak_normalize_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_void_p]),
     "bas_scale_by_peak_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
     "bas_mix_partials_f32": (_c_int, [_c_void_p, _c_int, _c_long, _c_long, _c_void_p, _c_void_p, _c_void_p]),
+    "bas_stream_epilogue_f32": (_c_int, [_c_void_p, _c_long, _c_int, _c_int, _c_long, _c_void_p, _c_void_p, _c_long,
+                                         _c_int, _c_int, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p]),
 }
 
 _lib = None
-ABI_VERSION = 2                                                      # BAS_ABI_VERSION of include/bas.h
+ABI_VERSION = 3                                                      # BAS_ABI_VERSION of include/bas.h
 DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libbas_hip_diag.so")   # -DBAS_DIAG build: reads BAS_FORCE_KERNEL (tests only)
 
 
@@ -80,6 +84,14 @@ def lib():
     return _lib
 
 
+def set_library(path):
+    """Route every later call of this process through another build of the ABI (profiling tools: the diagnostic or
+    the stamps build; `bench.py --lib`).  Returns the handle."""
+    global _lib
+    _lib = _load(path)
+    return _lib
+
+
 class use_library:
     """Context manager for tests and ablations: route every call of this process through another build of the
     same ABI (e.g. DIAG_LIB_PATH, the only build that honours BAS_FORCE_KERNEL) and restore the shipped one."""
@@ -104,6 +116,51 @@ def call(name, *args):
     rc = getattr(l, name)(*args)
     if rc != 0:
         raise BasError(name, rc, l.bas_last_error().decode(errors="replace"))
+
+
+class on_device:
+    """Make `device` the current HIP device for the calls inside: the library sizes its launches for the CURRENT
+    device (CU count, LDS limits) and launches on the stream it is given, so the two must agree even when the
+    caller's current device is another GPU.  No-op (no HIP call) when it already is."""
+
+    def __init__(self, device):
+        import torch
+        self.ctx = None
+        dev = torch.device(device)
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            self.ctx = torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
+
+
+def on_device_of(argname_or_index):
+    """Decorator: run the function with the device of its tensor argument (by position or keyword name; objects with a
+    `.device` attribute such as the device table count) as the current device."""
+    import functools
+
+    def deco(fn):
+        import inspect
+        names = list(inspect.signature(fn).parameters)
+        pos = names.index(argname_or_index) if isinstance(argname_or_index, str) else argname_or_index
+
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            obj = args[pos] if pos < len(args) else kwargs.get(names[pos])
+            dev = getattr(obj, "device", None)
+            if dev is None or getattr(dev, "type", "cuda") != "cuda":
+                return fn(*args, **kwargs)
+            with on_device(dev):
+                return fn(*args, **kwargs)
+        return wrapper
+    return deco
 
 
 def ptr(t):

@@ -14,7 +14,6 @@ Differences a caller can see (all documented in DESIGN.md):
     queries / many sources; the reference has none.
 """
 import math
-import os
 
 import numpy as np
 
@@ -51,8 +50,9 @@ class irs_and_delaydiffs:
         self.diffs_left, self.diffs_right = self.diffs[0], self.diffs[1]    # :40-41
         n_packed = _hip.lib().bas_table_packed_floats(self.ndir, self.M, self.upsampling)
         self.packed = torch.empty((n_packed,), dtype=torch.float32, device=device)   # [2][ndir][U][1+L]
-        _hip.call("bas_table_pack_f32", _hip.ptr(irs), self.ndir, self.M, self.upsampling,
-                  _hip.ptr(self.packed), _hip.current_stream(device))
+        with _hip.on_device(device):
+            _hip.call("bas_table_pack_f32", _hip.ptr(irs), self.ndir, self.M, self.upsampling,
+                      _hip.ptr(self.packed), _hip.current_stream(device))
 
 
 def load_irs_and_delaydiffs(filename='irs_and_delaydiffs_compensated_6.mat', samples_to_keep=512, device=None):
@@ -132,9 +132,10 @@ def delay_compensated_interpolation_with_delaydiff(irs_and_delaydiffs, before: i
     width = tbl.M if return_upsampled else tbl.L
     out = torch.empty((1, 2, width), dtype=torch.float32, device=dev)
     delays = torch.empty((1, 2), dtype=torch.float64, device=dev)
-    _hip.call("bas_ring_interp_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(pq), _hip.ptr(al), 1,
-              tbl.ndir, tbl.L, tbl.upsampling, int(bool(return_upsampled)), _hip.ptr(out), _hip.ptr(delays),
-              _hip.current_stream(dev))
+    with _hip.on_device(dev):
+        _hip.call("bas_ring_interp_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(pq), _hip.ptr(al), 1,
+                  tbl.ndir, tbl.L, tbl.upsampling, int(bool(return_upsampled)), _hip.ptr(out), _hip.ptr(delays),
+                  _hip.current_stream(dev))
     d = delays.cpu().numpy()
     return (d[0, 0], d[0, 1], out[0].cpu().numpy())
 
@@ -168,6 +169,12 @@ def interpolate_2d_params(tbl, idx, w, out=None, validate=True, ws=None):
     precomputed parameters: idx int32 [n,4], w float64 [n,3] (numpy or device
     tensors).  Returns a device tensor [n, 2, L] float32 (`out` if given).
     validate=False skips the index range check (a host<->device sync)."""
+    tbl = as_device_table(tbl)
+    with _hip.on_device(tbl.device):
+        return _interpolate_2d_params(tbl, idx, w, out, validate, ws)
+
+
+def _interpolate_2d_params(tbl, idx, w, out=None, validate=True, ws=None):
     import torch
     tbl = as_device_table(tbl)
     dev = tbl.device
@@ -224,6 +231,7 @@ def render_lengths(n, chunksize, ir_length):
     return in_length, in_length + ir_length - 1                             # :410
 
 
+@_hip.on_device_of("x")
 def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=None, accumulate=False,
                   events=None, ws=None):
     """Core launch: x [n_src, T_in] device float32 (T_in % K == 0), H [n_src, n_chunks+1, 2, L].
@@ -252,6 +260,7 @@ def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=Non
     return y, peak
 
 
+@_hip.on_device_of("x")
 def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix", out=None, events=None,
                          ws=None, ws_plans=None, fused=None):
     """interpolate_2d + render for precomputed parameters: x [n_src, T_in] device float32,
@@ -263,9 +272,7 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     dev = x.device
     n_src, t_in = x.shape
     lib = _hip.lib()
-    if fused is None:                                         # default: fused wherever the kernel serves the shape
-        fused = os.environ.get("BAS_FUSED", "1") != "0"
-    if fused:
+    if fused is None or fused:                                # default: fused wherever the kernel serves the shape
         fused = bool(lib.bas_render_fused_supported(n_src, t_in, chunksize, subchunksize, tbl.L)) and \
             tbl.upsampling >= 4 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
     n_q = idx.shape[0]
@@ -352,8 +359,22 @@ def render_sources(signals, chunksize, subchunksize, elev, azim, tbl, normalize=
     return y.t()
 
 
+def trajectory_branch(elev_azim_function):
+    """Which of the reference's two numeric branches a trajectory function selects (sphere.py:98-105, :119 under
+    NumPy >= 2): "pyfloat" when it returns a Python float / int azimuth for a Python-int time (the reference's own
+    presets circle_horizontal, circle_askew, spiral: apply_hrtf.py:585-586, :593 - comparisons and the ring weight
+    then run in float32), "f64" when it returns an np.float64 (presets built on np.sin / np.arctan), None for
+    anything else (np.float32 ...: only the scalar path reproduces those)."""
+    azim = elev_azim_function(0)[1]                                          # the reference's first call: t = 0 (:429)
+    if type(azim) is np.float64:
+        return "f64"
+    if type(azim) in (float, int):
+        return "pyfloat"
+    return None
+
+
 def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_function, irs_and_delaydiffs,
-                        verbose=False, vectorized=False):
+                        verbose=False, vectorized=False, branch="auto"):
     """Make `in_signal` sound as if its source moved along elev_azim_function
     (apply_hrtf.py:356-466): chunk IRs by interpolate_2d at t = 0, K, .., in_length,
     per-subchunk linear IR crossfade, direct FIR, overlap-add, float32, peak rule.
@@ -363,9 +384,13 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     elev_azim_function(t_samples) -> (elev, azim) in radians; it is called with the
     same scalar arguments as the reference calls it, so grid-node decisions follow the
     dtype it returns exactly as in the reference (sphere.py).  vectorized=True calls it
-    ONCE with the float64 array of all chunk times instead (it must broadcast) and uses
-    the float64 branch for every chunk: ~1000x less host time on long signals, identical
-    to the scalar path whenever the function returns np.float64 values.
+    ONCE with the float64 array of all chunk times instead (it must broadcast) and turns
+    the angles into interpolation parameters ON THE DEVICE (bas_traj_params_branch_f64):
+    ~1000x less host time on long signals.  `branch` ("f64", "pyfloat" or "auto") names
+    the reference's numeric branch to reproduce there: "auto" asks the function for its
+    value at t = 0 and follows the scalar type it returns (trajectory_branch), so the
+    reference's own presets render exactly as the scalar path renders them; a function
+    returning anything but Python floats / np.float64 falls back to the scalar path.
     """
     import torch
     is_tensor = isinstance(in_signal, torch.Tensor)
@@ -377,12 +402,20 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     n = int(in_signal.shape[0])
     in_length, out_length = render_lengths(n, chunksize, tbl.L)
     times = range(0, in_length + 1, chunksize)                               # :429, :435
+    if vectorized and branch == "auto":
+        branch = trajectory_branch(elev_azim_function)
+        vectorized = branch is not None
     if vectorized:
+        if branch not in sphere.BRANCHES:
+            raise ValueError("branch must be 'auto', 'f64' or 'pyfloat'")
         e, a = elev_azim_function(np.arange(0, in_length + 1, chunksize, dtype=np.float64))
         e, a = np.broadcast_arrays(np.asarray(e, dtype=np.float64), np.asarray(a, dtype=np.float64))
         if e.shape != (len(times),):
             e, a = np.broadcast_to(e, (len(times),)), np.broadcast_to(a, (len(times),))
-        idx, w = sphere.interpolation_params_batch(e, a)
+        if not (np.isfinite(e).all() and np.isfinite(a).all()):
+            raise ValueError("trajectory contains non-finite angles")
+        ea = torch.from_numpy(np.stack([e, a])).to(dev)                      # one H2D copy for both
+        idx_t, w_t = sphere.interpolation_params_device(ea[0], ea[1], branch=branch)
     else:
         idx = np.empty((len(times), 4), dtype=np.int32)
         w = np.empty((len(times), 3), dtype=np.float64)
@@ -390,11 +423,11 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
             idx[i], w[i] = sphere.interpolation_params(*elev_azim_function(t))
             if verbose:
                 print(' {:.1f}%           '.format(100 * t / max(in_length, 1)), end='\r')
+        idx_t, w_t = _params_to_device(tbl, idx, w)
     x = padded_rows(1, in_length, dev)                                       # :405-406
     src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
     x[0, :n] = src.to(device=dev, dtype=torch.float32)
-    idx_t, w_t = _params_to_device(tbl, idx, w)
-    y, _ = render_params_device(x, int(chunksize), int(subchunksize), tbl, idx_t, w_t, "mix")
+    y, _ = render_params_device(x, int(chunksize), int(subchunksize), tbl, idx_t.reshape(-1, 4), w_t.reshape(-1, 3), "mix")
     if verbose:
         print(' 100.0%      ')
     out = y.t()                                                              # (out_length, 2), F-ordered like :459
@@ -433,8 +466,9 @@ def make_signal_move(in_signal, chunksize: int, index_function, irs_and_delaydif
     pq_t = torch.from_numpy(pq).to(dev)
     al_t = torch.from_numpy(al).to(dev)
     H = torch.empty((1, n_chunks + 1, 2, tbl.L), dtype=torch.float32, device=dev)
-    _hip.call("bas_ring_interp_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(pq_t), _hip.ptr(al_t),
-              n_chunks + 1, tbl.ndir, tbl.L, tbl.upsampling, 0, _hip.ptr(H), None, _hip.current_stream(dev))
+    with _hip.on_device(dev):
+        _hip.call("bas_ring_interp_f32", _hip.ptr(tbl.packed), _hip.ptr(tbl.diffs), _hip.ptr(pq_t), _hip.ptr(al_t),
+                  n_chunks + 1, tbl.ndir, tbl.L, tbl.upsampling, 0, _hip.ptr(H), None, _hip.current_stream(dev))
     x = padded_rows(1, in_length, dev)                                       # :309-310
     src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
     x[0, :n] = src.to(device=dev, dtype=torch.float32)

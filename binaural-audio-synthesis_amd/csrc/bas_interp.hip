@@ -495,6 +495,12 @@ struct RingTable {
     int ring_count[10];
 };
 
+// PYF: the reference's branch for a PYTHON-FLOAT azimuth under NumPy >= 2 (sphere.py:98-105, :119): a Python float is a
+// "weak" scalar, so `index_azim[:,1] <= azim` and `(azim - before_azim) / (after_azim - before_azim)` are evaluated in the
+// table's float32 - the azimuth is rounded to binary32 first (after the binary64 modulo of :86), compared in binary32,
+// and the weight is a binary32 quotient of binary32 differences.  That is what the reference's own trajectory presets
+// (circle_horizontal, circle_askew, spiral: apply_hrtf.py:585-586, :593) feed it.
+template <bool PYF>
 __device__ __forceinline__ void ring_lookup(const RingTable &R, const float *__restrict__ node_az, int ring,
                                              double az, int &before, int &after, double &a) {
     if (ring == 9) {                                         // pole: sphere.py:92-93
@@ -503,18 +509,21 @@ __device__ __forceinline__ void ring_lookup(const RingTable &R, const float *__r
         return;
     }
     const int start = R.ring_start[ring], count = R.ring_count[ring];
+    const float az32 = (float)az;                            // round to nearest even, as numpy converts the weak scalar
     int j = 0;                                               // last node <= az (node 0 is azimuth 0)
     for (int i = 1; i < count; ++i)
-        if ((double)node_az[start + i] <= az) j = i;
+        if (PYF ? node_az[start + i] <= az32 : (double)node_az[start + i] <= az) j = i;
     const bool wrap = j + 1 >= count;
     const float b32 = node_az[start + j];
     const float a32 = wrap ? (float)(2.0 * 3.14159265358979323846) : node_az[start + j + 1];
     const float den = __fsub_rn(a32, b32);                   // float32 subtraction, as sphere.py:119 evaluates it
     before = start + j;
     after = wrap ? start : start + j + 1;
-    a = (az - (double)b32) / (double)den;
+    if (PYF) a = (double)__fdiv_rn(__fsub_rn(az32, b32), den);
+    else a = (az - (double)b32) / (double)den;
 }
 
+template <bool PYF>
 __global__ __launch_bounds__(256) void bas_traj_params_kernel(const double *__restrict__ elev,
                                                                 const double *__restrict__ azim, long n,
                                                                 RingTable R, const float *__restrict__ node_az,
@@ -530,8 +539,8 @@ __global__ __launch_bounds__(256) void bas_traj_params_kernel(const double *__re
         while (lo > 0 && R.ring_elev[lo] > e) --lo;
         int tb, taf, bb, baf;
         double ta, ba;
-        ring_lookup(R, node_az, hi, z, tb, taf, ta);
-        ring_lookup(R, node_az, lo, z, bb, baf, ba);
+        ring_lookup<PYF>(R, node_az, hi, z, tb, taf, ta);
+        ring_lookup<PYF>(R, node_az, lo, z, bb, baf, ba);
         const double span = R.ring_elev[hi] - R.ring_elev[lo];
         const double a = span > 0.0 ? (e - R.ring_elev[lo]) / span : 0.0;
         idx[4 * q + 0] = tb; idx[4 * q + 1] = taf; idx[4 * q + 2] = bb; idx[4 * q + 3] = baf;
@@ -539,24 +548,44 @@ __global__ __launch_bounds__(256) void bas_traj_params_kernel(const double *__re
     }
 }
 
-extern "C" int bas_traj_params_f64(const double *elev, const double *azim, long n, const double *ring_elev,
-                                   const int32_t *ring_start, const int32_t *ring_count, const float *node_az,
-                                   int32_t *idx, double *w, bas_stream_t stream) {
-    BAS_REQUIRE(ring_elev && ring_start && ring_count && node_az, BAS_E_NULL, "bas_traj_params_f64: null ring table");
-    BAS_REQUIRE(n >= 0, BAS_E_SHAPE, "bas_traj_params_f64: n < 0");
+static int traj_params_launch(const char *who, const double *elev, const double *azim, long n, const double *ring_elev,
+                              const int32_t *ring_start, const int32_t *ring_count, const float *node_az,
+                              int32_t *idx, double *w, int branch, bas_stream_t stream) {
+    BAS_REQUIRE(ring_elev && ring_start && ring_count && node_az, BAS_E_NULL, "%s: null ring table", who);
+    BAS_REQUIRE(n >= 0, BAS_E_SHAPE, "%s: n < 0", who);
+    BAS_REQUIRE(branch == BAS_BRANCH_F64 || branch == BAS_BRANCH_PYFLOAT, BAS_E_SHAPE,
+                "%s: branch must be BAS_BRANCH_F64 (0) or BAS_BRANCH_PYFLOAT (1), got %d", who, branch);
     if (n == 0) return 0;
-    BAS_REQUIRE(elev && azim && idx && w, BAS_E_NULL, "bas_traj_params_f64: null pointer");
+    BAS_REQUIRE(elev && azim && idx && w, BAS_E_NULL, "%s: null pointer", who);
     RingTable R;
     for (int i = 0; i < 10; ++i) {
         R.ring_elev[i] = ring_elev[i];
         R.ring_start[i] = ring_start[i];
         R.ring_count[i] = ring_count[i];
         BAS_REQUIRE(R.ring_count[i] > 0 && R.ring_start[i] >= 0 && R.ring_start[i] + R.ring_count[i] <= 187,
-                    BAS_E_SHAPE, "bas_traj_params_f64: ring %d out of the 187-direction table", i);
+                    BAS_E_SHAPE, "%s: ring %d out of the 187-direction table", who, i);
     }
     long blocks = (n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bas_traj_params_kernel, dim3((unsigned)blocks), dim3(256), 0, bas_stream(stream), elev, azim,
-                       n, R, node_az, idx, w);
-    return bas_check_launch("bas_traj_params_f64");
+    if (branch == BAS_BRANCH_PYFLOAT)
+        hipLaunchKernelGGL(bas_traj_params_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, bas_stream(stream), elev,
+                           azim, n, R, node_az, idx, w);
+    else
+        hipLaunchKernelGGL(bas_traj_params_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, bas_stream(stream), elev,
+                           azim, n, R, node_az, idx, w);
+    return bas_check_launch(who);
+}
+
+extern "C" int bas_traj_params_f64(const double *elev, const double *azim, long n, const double *ring_elev,
+                                   const int32_t *ring_start, const int32_t *ring_count, const float *node_az,
+                                   int32_t *idx, double *w, bas_stream_t stream) {
+    return traj_params_launch("bas_traj_params_f64", elev, azim, n, ring_elev, ring_start, ring_count, node_az, idx, w,
+                              BAS_BRANCH_F64, stream);
+}
+
+extern "C" int bas_traj_params_branch_f64(const double *elev, const double *azim, long n, const double *ring_elev,
+                                          const int32_t *ring_start, const int32_t *ring_count, const float *node_az,
+                                          int32_t *idx, double *w, int branch, bas_stream_t stream) {
+    return traj_params_launch("bas_traj_params_branch_f64", elev, azim, n, ring_elev, ring_start, ring_count, node_az,
+                              idx, w, branch, stream);
 }

@@ -26,14 +26,16 @@ def _hip_mix_partials(parts):
     p, _, t = parts.shape
     y = torch.empty((2, t), dtype=torch.float32, device=parts.device)
     peak = torch.empty((1,), dtype=torch.float32, device=parts.device)
-    _hip.call("bas_mix_partials_f32", _hip.ptr(parts), p, 2 * t, 2 * t, _hip.ptr(y), _hip.ptr(peak),
-              _hip.current_stream(parts.device))
+    with _hip.on_device(parts.device):
+        _hip.call("bas_mix_partials_f32", _hip.ptr(parts), p, 2 * t, 2 * t, _hip.ptr(y), _hip.ptr(peak),
+                  _hip.current_stream(parts.device))
     return y, peak
 
 
 def _hip_scale_by_peak(y, peak):
     from . import _hip
-    _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), y.numel(), _hip.ptr(peak), _hip.current_stream(y.device))
+    with _hip.on_device(y.device):
+        _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), y.numel(), _hip.ptr(peak), _hip.current_stream(y.device))
     return y
 
 
@@ -50,9 +52,9 @@ def gather_mix(partial, group=None, dst=0, mix_fn=None, scale_fn=None, normalize
     scale_fn = scale_fn or _hip_scale_by_peak
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     partial = partial.contiguous()                             # mix_fn and the collective assume dense [2, T]
-    if world == 1:
+    if not dist.is_initialized():
         y, peak = mix_fn(partial.unsqueeze(0))
-    else:
+    else:                                                      # (also for a one-rank group: the same code path at every size)
         rank = dist.get_rank(group)
         # gloo cannot gather device tensors: stage through host memory (debugging / rehearsal on boxes
         # without RCCL peers; the production backend "nccl" gathers device to device over xGMI)
@@ -127,9 +129,9 @@ def render_time_sharded(signals, chunksize, subchunksize, elev, azim, tbl, ir_le
     lo = (c0 - h0) * K
     hi = (c1 - h0) * K + (L - 1 if rank == world - 1 else 0)
     mine = y[lo:hi].contiguous()
-    if world == 1:
+    if not dist.is_initialized():
         full = mine
-    else:
+    else:                                                     # (also for a one-rank group: the same code path at every size)
         sizes = [(shard_time(n_chunks, world, r)[1] - shard_time(n_chunks, world, r)[0]) * K +
                  (L - 1 if r == world - 1 else 0) for r in range(world)]
         pad = max(sizes)

@@ -159,8 +159,13 @@ _NODES64 = [index_elev_azim[s:s + c, 2].astype(np.float64) for s, c in zip(RING_
 _NODES32 = [index_elev_azim[s:s + c, 2] for s, c in zip(RING_START, RING_COUNTS)]
 
 
-def _ring_params_batch(ring, azim_mod):
-    """before, after (int32) and a (float64) for ring indices `ring` (0..9) and wrapped azimuths."""
+BRANCHES = {"f64": 0, "pyfloat": 1}                 # BAS_BRANCH_F64 / BAS_BRANCH_PYFLOAT of include/bas.h
+
+
+def _ring_params_batch(ring, azim_mod, branch="f64"):
+    """before, after (int32) and a (float64) for ring indices `ring` (0..9) and wrapped azimuths.
+    branch "pyfloat": the reference's arithmetic for a Python-float azimuth under NumPy >= 2 (sphere.py:98-105,
+    :119 with a weak scalar): azimuth rounded to float32, float32 comparisons, float32 weight."""
     n = azim_mod.shape[0]
     before = np.empty(n, dtype=np.int32)
     after = np.empty(n, dtype=np.int32)
@@ -176,24 +181,35 @@ def _ring_params_batch(ring, azim_mod):
             continue
         az = azim_mod[sel]
         start, count = RING_START[r], RING_COUNTS[r]
-        j = np.searchsorted(_NODES64[r], az, side="right") - 1     # last node <= azim (float64 compare)
+        if branch == "pyfloat":
+            az = az.astype(np.float32)              # the weak Python scalar takes the array's dtype
+            j = np.searchsorted(_NODES32[r], az, side="right") - 1  # last node <= azim (float32 compare)
+        else:
+            j = np.searchsorted(_NODES64[r], az, side="right") - 1  # last node <= azim (float64 compare)
         wrap = j + 1 >= count
         ja = np.where(wrap, 0, j + 1)
         b32 = _NODES32[r][j]
         a32 = np.where(wrap, np.float32(2 * np.pi), _NODES32[r][ja]).astype(np.float32)
-        denom = (a32 - b32).astype(np.float64)      # float32 subtraction, as sphere.py:119 evaluates it
+        den32 = a32 - b32                           # float32 subtraction, as sphere.py:119 evaluates it
         before[sel] = start + j
         after[sel] = start + ja
-        a[sel] = (az - b32.astype(np.float64)) / denom
+        if branch == "pyfloat":
+            a[sel] = ((az - b32) / den32).astype(np.float64)        # float32 throughout
+        else:
+            a[sel] = (az - b32.astype(np.float64)) / den32.astype(np.float64)
     return before, a, after
 
 
-def interpolation_params_batch(elev, azim):
+def interpolation_params_batch(elev, azim, branch="f64"):
     """Vectorised interpolation_params for float64 arrays of any (equal) shape.
 
     Returns idx int32 [..., 4] = (top_before, top_after, bot_before, bot_after) and
     w float64 [..., 3] = (top_alpha, bot_alpha, a): the inputs of bas_interp2d_f32.
+    branch: "f64" = what the reference computes when its trajectory function returns np.float64 azimuths,
+    "pyfloat" = when it returns Python floats (the reference's own presets; see _ring_params_batch).
     """
+    if branch not in BRANCHES:
+        raise ValueError("branch must be 'f64' or 'pyfloat'")
     elev = np.asarray(elev, dtype=np.float64)
     azim = np.asarray(azim, dtype=np.float64)
     elev, azim = np.broadcast_arrays(elev, azim)
@@ -207,8 +223,8 @@ def interpolation_params_batch(elev, azim):
     hi = np.minimum(hi, 9)                                        # above +90: clamp (apply_hrtf.py:206-209)
     lo = np.maximum(lo, 0)                                        # below -45: clamp (:201-204)
     lower, higher = _AVAILABLE_ELEVS[lo], _AVAILABLE_ELEVS[hi]
-    tb, ta, taf = _ring_params_batch(hi, z)
-    bb, ba, baf = _ring_params_batch(lo, z)
+    tb, ta, taf = _ring_params_batch(hi, z, branch)
+    bb, ba, baf = _ring_params_batch(lo, z, branch)
     span = higher - lower
     a = np.where(span > 0, (e - lower) / np.where(span > 0, span, 1.0), 0.0)
     if ((a < 0) | (a > 1)).any():
@@ -235,11 +251,13 @@ def _ring_args():
     return _RING_ARGS[3:]
 
 
-def interpolation_params_device(elev, azim, out=None):
-    """interpolation_params_batch on the GPU (bas_traj_params_f64): elev/azim are float64 device
+def interpolation_params_device(elev, azim, out=None, branch="f64"):
+    """interpolation_params_batch on the GPU (bas_traj_params_branch_f64): elev/azim are float64 device
     tensors of equal shape; returns device tensors idx int32 [..., 4], w float64 [..., 3] (written into
     `out` = (idx, w) when given: contiguous tensors of those shapes, no allocation per call).
     Non-finite angles are not diagnosed here (the host form raises ValueError)."""
+    if branch not in BRANCHES:
+        raise ValueError("branch must be 'f64' or 'pyfloat'")
     import torch
     from . import _hip
     assert elev.is_cuda and elev.dtype == torch.float64 and azim.shape == elev.shape and azim.dtype == torch.float64
@@ -258,6 +276,7 @@ def interpolation_params_device(elev, azim, out=None):
         assert idx.is_contiguous() and w.is_contiguous() and idx.numel() == 4 * n and w.numel() == 3 * n
         assert idx.dtype == torch.int32 and w.dtype == torch.float64 and idx.device == dev and w.device == dev
     ring_elev, ring_start, ring_count = _ring_args()
-    _hip.call("bas_traj_params_f64", _hip.ptr(e), _hip.ptr(z), n, ring_elev, ring_start, ring_count,
-              _hip.ptr(nodes), _hip.ptr(idx), _hip.ptr(w), _hip.current_stream(dev))
+    with _hip.on_device(dev):
+        _hip.call("bas_traj_params_branch_f64", _hip.ptr(e), _hip.ptr(z), n, ring_elev, ring_start, ring_count,
+                  _hip.ptr(nodes), _hip.ptr(idx), _hip.ptr(w), BRANCHES[branch], _hip.current_stream(dev))
     return idx.reshape(tuple(elev.shape) + (4,)), w.reshape(tuple(elev.shape) + (3,))

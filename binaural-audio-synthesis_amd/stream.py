@@ -3,10 +3,10 @@
 The reference renders one whole signal held in RAM (apply_hrtf.py:405-414) but its chunk
 loop is causal (:431-453): output sample n depends on inputs n-L+1 .. n and on the chunk
 IRs around them.  StreamRenderer therefore keeps, per source, the last `halo` input samples
-(halo = (L-1) rounded up to a multiple of the chunk size) and the interpolation parameters
-of the chunk boundaries inside that halo; every call renders [halo | new block] with the
-same kernels and emits exactly the outputs the new block completes.  Concatenating the
-emitted blocks (plus `finish()`) reproduces the whole-signal render sample for sample
+(halo = (L-1) rounded up to a multiple of the chunk size) and the trajectory angles of the
+chunk boundaries inside that halo; every call renders [halo | new block] with the same
+kernels and emits exactly the outputs the new block completes.  Concatenating the emitted
+blocks (plus `finish()`) reproduces the whole-signal render sample for sample
 (tests/test_gpu_parity.py::test_streaming_equals_whole).
 
 The reference's peak rule (apply_hrtf.py:462-464) is global over the finished signal and
@@ -15,21 +15,29 @@ and tracks the running peak (`peak`), so a caller can scale afterwards exactly a
 reference would.  Long streams (BASELINE config 5: 1 h at 48 kHz, 1024 sources) never
 materialise more than one block of inputs, chunk IRs and outputs.
 
-All per-block state lives in buffers that are allocated once per block size, and one block
-is a fixed sequence of stream-ordered calls on them (angles -> parameters, read plans, fused
-FIR, carry copies, running peak).  From the second block of a size on that sequence is
-replayed as ONE hipGraph launch (graph=True, the default): a real-time caller feeding
-512-sample blocks pays one graph launch per block instead of a dozen Python-level launches.
+One block = five launches on persistent buffers: angles -> parameters (bas_traj_params_f64),
+read plans, the fused chunk-IR / FIR / mix kernel, its slab reduce, and
+bas_stream_epilogue_f32 (running peak over the emitted samples + every carry copy).  With
+graph=True those are replayed as ONE hipGraph launch.  `prepare(B)` lays the buffers out and
+captures the graph BEFORE streaming starts (capture synchronises the device and must not
+race with allocations of other threads: keep it out of the real-time phase); without it the
+first block of a size runs as plain launches and the second one captures.
+
+Why the halo is a whole number of CHUNKS (K) rather than L-1 rounded to 32: the kernels
+take windows whose first sample lies on a chunk boundary (the crossfade position of an input
+is its offset inside its chunk, apply_hrtf.py:442), and their work is quantised by output
+tiles of 2048 samples anyway - a 512-sample block with a 512-sample halo is ONE tile per
+source, exactly as it would be with a 128-sample halo.
 """
-from . import sphere
+from . import _hip
 from .apply_hrtf import as_device_table, render_angles_device
 
 
 class StreamRenderer:
     def __init__(self, tbl, n_src, chunksize, subchunksize, graph=True, copy_out=True):
-        """graph: replay each block as one captured hipGraph (from the second block of a given size on).
-        copy_out: process() returns a fresh tensor (True) or a view of the renderer's output buffer that the
-        next process() call overwrites (False: no copy kernel; for callers that consume each block at once)."""
+        """graph: replay each block as one captured hipGraph (captured by prepare(), else on the second block of a
+        size).  copy_out: process() returns a fresh tensor (True) or a view of the renderer's output buffer that
+        the next process() call overwrites (False: no copy kernel; for callers that consume each block at once)."""
         import torch
         assert chunksize % subchunksize == 0, 'subchunksize does not divide chunksize evenly'
         self.tbl = as_device_table(tbl)
@@ -45,10 +53,14 @@ class StreamRenderer:
         self._B = None                                    # block size the per-block buffers are laid out for
         self._graph = None
         self._halo_params = None                          # (elev, azim) [n_src, nh] of the halo's boundaries across a re-layout
-        self._first = True
-        self._peak_dev = torch.zeros((), dtype=torch.float32, device=dev)
+        self._started = False                             # a block has been rendered
+        # the angles at the END of the last block, for finish(): their own buffer, so that a change of block size
+        # (which re-allocates the per-block angle buffers) cannot lose them
+        self._last = torch.zeros((2, self.n_src), dtype=torch.float64, device=dev)
+        self._peak_dev = torch.zeros((1,), dtype=torch.float32, device=dev)
         self.samples_in = 0
         self._finished = False
+        self._events = None                               # (begin, end) raw hipEvent_t around the FIR kernel of plain-launch blocks (bench.py)
 
     # ---- buffers ---------------------------------------------------------------------------------------
     def _reserve(self, B):
@@ -63,16 +75,16 @@ class StreamRenderer:
     def _layout(self, B):
         """Per-block buffers for blocks of B samples (kept until another size arrives)."""
         import torch
-        from . import _hip
         if self._B == B:
             return
         dev, n, nh = self.tbl.device, self.n_src, self.nh
         nb = B // self.K + 1
-        if self._B is not None and not self._first:       # carry the halo's angles into the new layout
+        if self._B is not None and self._started:         # carry the halo's angles into the new layout
             self._halo_params = (self._elev_all[:, :nh].clone(), self._azim_all[:, :nh].clone())
         self._reserve(B)
         self._B, self._nb, self._graph, self._blocks_in_layout = B, nb, None, 0
-        # trajectory at the chunk boundaries t0-halo .. t0+B: [halo part carried | this block's part]
+        # trajectory at the chunk boundaries t0-halo .. t0+B: [halo part carried | this block's part].  Zero is a
+        # valid direction: before the first block the halo holds silence and its chunk IRs only multiply zeros.
         self._elev_all = torch.zeros((n, nh + nb), dtype=torch.float64, device=dev)
         self._azim_all = torch.zeros((n, nh + nb), dtype=torch.float64, device=dev)
         if self._halo_params is not None:
@@ -83,15 +95,17 @@ class StreamRenderer:
         self._y = torch.empty((2, self.halo + B + self.tbl.L - 1), dtype=torch.float32, device=dev)
         lib = _hip.lib()
         t_in = self.halo + B
-        wb = max(lib.bas_render_workspace_bytes(n, t_in, self.K, self.S, self.tbl.L),
-                 lib.bas_render_fused_workspace_bytes(n, t_in, self.K, self.S, self.tbl.L))
+        with _hip.on_device(dev):
+            wb = max(lib.bas_render_workspace_bytes(n, t_in, self.K, self.S, self.tbl.L),
+                     lib.bas_render_fused_workspace_bytes(n, t_in, self.K, self.S, self.tbl.L))
         self._ws = torch.empty((wb,), dtype=torch.uint8, device=dev)
         self._ws_plans = torch.empty((lib.bas_interp2d_workspace_bytes(n * (nh + nb)),), dtype=torch.uint8, device=dev)
 
     def input_view(self, B):
         """Device view [n_src, B] of the renderer's own input buffer.  A producer (decoder, H2D copy,
         another kernel) that writes the next block here and passes this view to process() saves the
-        staging copy of the block; the view is valid until the next input_view() call with a larger B."""
+        staging copy of the block; the view is valid until the next input_view() call with a larger B.
+        Growing the buffer allocates and drops the captured graph: size it once, before prepare()."""
         self._reserve(B)
         return self._xbuf[:, self.halo:self.halo + B]
 
@@ -105,25 +119,54 @@ class StreamRenderer:
     # ---- one block -------------------------------------------------------------------------------------
     def _block_body(self):
         """The stream-ordered work of one block on the per-block buffers (captured into the hipGraph)."""
-        import torch
         B, nb, nh, halo = self._B, self._nb, self.nh, self.halo
-        if self._first:                                   # the halo holds silence, any valid direction will do
-            self._elev_all[:, :nh] = self._elev_all[:, nh:nh + 1]
-            self._azim_all[:, :nh] = self._azim_all[:, nh:nh + 1]
+        dev = self.tbl.device
         x = self._xbuf[:, :halo + B]
         # a3, read plans, chunk IRs + FIR + mix (or the stored-IR path for other sizes)
         render_angles_device(x, self.K, self.S, self.tbl, self._elev_all, self._azim_all, normalize="none",
-                             out=self._y, ws=self._ws, ws_plans=self._ws_plans, params=(self._idx, self._w))
-        out = self._y[:, halo:halo + B]
-        self._peak_dev.copy_(torch.maximum(self._peak_dev, out.abs().max()))
-        # carry: last `halo` inputs and the angles at their chunk boundaries (t0+B-halo .. t0+B-K)
-        if halo:
-            tail = x[:, B:B + halo]
-            self._xbuf[:, :halo] = tail.clone() if B < halo else tail            # ranges overlap only if B < halo
-            ea, aa = self._elev_all[:, nb - 1:nb - 1 + nh], self._azim_all[:, nb - 1:nb - 1 + nh]
-            overlap = nb - 1 < nh
-            self._elev_all[:, :nh] = ea.clone() if overlap else ea
-            self._azim_all[:, :nh] = aa.clone() if overlap else aa
+                             out=self._y, ws=self._ws, ws_plans=self._ws_plans, params=(self._idx, self._w),
+                             events=self._events)
+        # running peak over the emitted samples + carry of the last `halo` inputs and of the angles at their
+        # chunk boundaries (t0+B-halo .. t0+B-K) + the angles at t0+B for finish(): one launch
+        with _hip.on_device(dev):
+            _hip.call("bas_stream_epilogue_f32", _hip.ptr(self._xbuf), self._xbuf.stride(0), self.n_src, halo, B,
+                      _hip.ptr(self._elev_all), _hip.ptr(self._azim_all), self._elev_all.stride(0), nh, nb,
+                      _hip.ptr(self._last), _hip.ptr(self._y), self._y.stride(0), _hip.ptr(self._peak_dev),
+                      _hip.current_stream(dev))
+
+    def _capture(self):
+        import torch
+        g = torch.cuda.CUDAGraph()
+        # thread_local: allocations or copies of OTHER threads (a decoder filling input_view()) do not invalidate
+        # the capture; the capture's own allocations come from the graph's private pool
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            self._block_body()
+        self._graph = g
+
+    def prepare(self, B):
+        """Lay out the buffers for blocks of B samples, run one block on silence as a warm-up (first-use costs of the
+        kernels) and, with graph=True, capture the block's hipGraph - all BEFORE streaming starts, so that no
+        process() call ever pays for a capture (which synchronises the device for milliseconds).  The carried
+        state (input halo, halo angles, end angles, running peak, sample count) is left exactly as it was.
+        Call again after a change of block size or after input_view() had to grow."""
+        import torch
+        assert not self._finished, "stream already finished"
+        assert B % self.K == 0 and B > 0, 'block length must be a positive multiple of the chunk size'
+        self._layout(B)
+        halo, nh = self.halo, self.nh
+        keep = (self._xbuf[:, :halo + B].clone(), self._elev_all.clone(), self._azim_all.clone(), self._last.clone(),
+                self._peak_dev.clone())
+        self._xbuf[:, halo:halo + B].zero_()
+        self._block_body()                                # plain launches: warm-up
+        if self.graph_enabled and self._graph is None:
+            self._capture()                               # (records the launches, does not execute them)
+        torch.cuda.synchronize(self.tbl.device)
+        self._xbuf[:, :halo + B].copy_(keep[0])
+        self._elev_all.copy_(keep[1])
+        self._azim_all.copy_(keep[2])
+        self._last.copy_(keep[3])
+        self._peak_dev.copy_(keep[4])
+        self._blocks_in_layout = max(self._blocks_in_layout, 1)
 
     def process(self, block, elev, azim):
         """block: [n_src, B] (B a multiple of the chunk size); elev/azim: float64 [n_src, B/K + 1],
@@ -135,7 +178,6 @@ class StreamRenderer:
         assert blk.dim() == 2 and blk.shape[0] == self.n_src, 'block must be [n_src, B]'
         B = blk.shape[1]
         assert B % self.K == 0 and B > 0, 'block length must be a positive multiple of the chunk size'
-        dev = self.tbl.device
         self._layout(B)
         nb = self._nb
         for src, dst in ((elev, self._elev_all[:, self.nh:]), (azim, self._azim_all[:, self.nh:])):
@@ -149,16 +191,14 @@ class StreamRenderer:
             blk.data_ptr() == x_dst.data_ptr()
         if not in_place:
             x_dst.copy_(blk)
-        if self._first or not self.graph_enabled or (self._graph is None and self._blocks_in_layout == 0):
-            self._block_body()                            # first block of a size: plain launches (also the warm-up)
-            self._first = False
-        else:
-            if self._graph is None:                       # second consecutive block of this size: capture once
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._block_body()
-                self._graph = g
+        if self._graph is not None:
             self._graph.replay()
+        elif not self.graph_enabled or self._blocks_in_layout == 0:
+            self._block_body()                            # no prepare(): the first block of a size runs plain (warm-up)
+        else:
+            self._capture()                               # ... and the second one captures (a device synchronisation:
+            self._graph.replay()                          # real-time callers use prepare() instead)
+        self._started = True
         self._blocks_in_layout += 1
         self.samples_in += B
         out = self._y[:, self.halo:self.halo + B].t()
@@ -167,24 +207,27 @@ class StreamRenderer:
     @property
     def peak(self):
         """max |sample| emitted so far (reads back one float)."""
-        return float(self._peak_dev)
+        return float(self._peak_dev[0])
 
     def finish(self):
         """Emit the last L-1 samples (the tail the reference appends, apply_hrtf.py:410): render one
         silent chunk behind the stream.  The chunk boundary at the stream's end was supplied by the
-        last process() call; the one after it only multiplies silence."""
+        last process() call (kept in its own buffer across changes of block size); the one after it only
+        multiplies silence."""
         import torch
         assert not self._finished, "stream already finished"
-        if self._first:
+        if not self._started:
             raise RuntimeError("finish() before any block")
-        L, nh, nb = self.tbl.L, self.nh, self._nb
+        L, nh = self.tbl.L, self.nh
         dev = self.tbl.device
-        e_last, a_last = self._elev_all[:, nh + nb - 1:nh + nb], self._azim_all[:, nh + nb - 1:nh + nb]
-        elev = torch.cat([self._elev_all[:, :nh], e_last, e_last], dim=1).contiguous()
-        azim = torch.cat([self._azim_all[:, :nh], a_last, a_last], dim=1).contiguous()
+        e_last, a_last = self._last[0].reshape(-1, 1), self._last[1].reshape(-1, 1)
+        e_halo, a_halo = self._elev_all[:, :nh], self._azim_all[:, :nh]   # (a re-layout carries them over)
+        elev = torch.cat([e_halo, e_last, e_last], dim=1).contiguous()
+        azim = torch.cat([a_halo, a_last, a_last], dim=1).contiguous()
         x = torch.cat([self._xbuf[:, :self.halo], torch.zeros((self.n_src, self.K), dtype=torch.float32, device=dev)], dim=1)
         y, _ = render_angles_device(x, self.K, self.S, self.tbl, elev, azim, normalize="none")
         out = y[:, self.halo:self.halo + L - 1]
-        self._peak_dev = torch.maximum(self._peak_dev, out.abs().max()) if out.numel() else self._peak_dev
+        if out.numel():
+            self._peak_dev = torch.maximum(self._peak_dev, out.abs().max().reshape(1))
         self._finished = True
         return out.t()

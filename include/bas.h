@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BAS_ABI_VERSION 2
+#define BAS_ABI_VERSION 3
 
 #define BAS_E_NULL      (-1)   /* a required pointer is NULL                    */
 #define BAS_E_SHAPE     (-2)   /* inconsistent or unsupported sizes             */
@@ -94,6 +94,24 @@ int bas_ring_interp_f32(const float *packed, const double *diffs, const int32_t 
 int bas_traj_params_f64(const double *elev, const double *azim, long n, const double *ring_elev,
                         const int32_t *ring_start, const int32_t *ring_count, const float *node_az,
                         int32_t *idx, double *w, bas_stream_t stream);
+
+/* The same with the reference's OTHER numeric branch selectable.  Which one the reference takes
+ * depends on the scalar type its trajectory function returns (NumPy >= 2 promotion rules):
+ *   BAS_BRANCH_F64      azimuth is an np.float64: node comparisons (sphere.py:103-104) and the weight
+ *                       a = (azim - az_b) / (az_a - az_b) (:119) in binary64 against the float32 node
+ *                       values (= bas_traj_params_f64);
+ *   BAS_BRANCH_PYFLOAT  azimuth is a Python float (what the reference's own presets circle_horizontal,
+ *                       circle_askew and spiral return, apply_hrtf.py:585-586, :593): the azimuth is
+ *                       wrapped in binary64 (:86), then rounded to binary32; comparisons and the weight
+ *                       are binary32 (the weight is returned widened to f64).
+ * The elevation bracket and the vertical weight (apply_hrtf.py:199-215, :261-266) are binary64 in
+ * both branches, as in the reference. */
+#define BAS_BRANCH_F64     0
+#define BAS_BRANCH_PYFLOAT 1
+int bas_traj_params_branch_f64(const double *elev, const double *azim, long n,
+                               const double *ring_elev, const int32_t *ring_start,
+                               const int32_t *ring_count, const float *node_az, int32_t *idx,
+                               double *w, int branch, bas_stream_t stream);
 
 /* ---- a6: interpolate_2d (apply_hrtf.py:171-281), batched --------------------
  * The angle -> (indices, weights) step (sphere.py:78-121 and the elevation
@@ -192,6 +210,24 @@ int bas_scale_by_peak_f32(float *y, long n, const float *peak, bas_stream_t stre
  * Used on the root rank after the RCCL gather of the per-GPU partial mixes. */
 int bas_mix_partials_f32(const float *parts, int n_parts, long part_stride, long n, float *y,
                          float *peak, bas_stream_t stream);
+
+/* ---- streaming: carried state of block-wise rendering -------
+ * No reference counterpart: the reference renders one whole signal held in RAM
+ * (apply_hrtf.py:405-414); its chunk loop is causal (:431-453), so a stream is rendered
+ * as windows [halo | block] with halo = (L-1) rounded up to chunks.  After a window's
+ * render this ONE launch moves everything that crosses the block boundary:
+ *   running_peak = max(running_peak, max|y[e][halo .. halo+B)|)   (the peak of
+ *       apply_hrtf.py:462 over the samples EMITTED so far; may be NULL)
+ *   x[s][0 .. halo)  = x[s][B .. B+halo)           (input halo, every source)
+ *   last[0][s], last[1][s] = elev/azim[s][nh+nb-1] (the angles at the block's end)
+ *   elev/azim[s][0 .. nh) = elev/azim[s][nb-1 .. nb-1+nh)   (halo chunk boundaries)
+ * x [n_src] rows, stride x_stride >= halo+B; elev/azim f64 [n_src] rows of nh+nb angles,
+ * stride ang_stride; last f64 [2][n_src]; y [2] rows of the window's output, stride
+ * y_stride; nh = halo / K, nb = B / K + 1. */
+int bas_stream_epilogue_f32(float *x, long x_stride, int n_src, int halo, long B, double *elev,
+                            double *azim, long ang_stride, int nh, int nb, double *last,
+                            const float *y, long y_stride, float *running_peak,
+                            bas_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,286 @@
+"""GPU parity tests added in round 3 (missing 3, 5, 6; next-round items 3a, 5, 6).
+
+Tolerance: REL = 1e-5 norm-relative (max|got - want| / max|want|), as everywhere; integer / index results and
+everything that is only re-ordered bookkeeping must be bit-identical.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden, rel_err
+from oracle import bas_oracle as orc
+import binaural_audio_synthesis_amd as bas
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def _device_table(h):
+    return bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+
+
+# ---------------------------------------------------------------------------
+# a3 on the device: the float32 ("pyfloat") branch
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["pyfloat", "f64"])
+def test_device_params_branch_against_reference_goldens(kind):
+    """bas_traj_params_branch_f64 against values the unmodified reference produced for Python-float and np.float64
+    azimuths (tests/golden/azim_params.npz; the fixture's elevations are database rings: top ring = bottom ring)."""
+    import torch
+    g = golden("azim_params.npz")
+    idx, w = bas.sphere.interpolation_params_device(torch.from_numpy(g["elev"].astype(np.float64)).cuda(),
+                                                    torch.from_numpy(g["azim"].astype(np.float64)).cuda(), branch=kind)
+    idx, w = idx.cpu().numpy(), w.cpu().numpy()
+    assert np.array_equal(idx[:, 0], g[f"before_{kind}"]) and np.array_equal(idx[:, 1], g[f"after_{kind}"])
+    assert np.array_equal(idx[:, 2], g[f"before_{kind}"]) and np.array_equal(idx[:, 3], g[f"after_{kind}"])
+    assert np.array_equal(w[:, 0], g[f"a_{kind}"]) and np.array_equal(w[:, 1], g[f"a_{kind}"])
+    assert not w[:, 2].any()
+
+
+def test_device_pyfloat_branch_is_bit_identical_to_host():
+    import torch
+    rng = np.random.default_rng(13)
+    e = rng.uniform(-1.4, 2.0, 400000)
+    z = rng.uniform(-50, 100, 400000)
+    nodes = np.deg2rad(np.arange(0, 361, 15, dtype=np.float64))
+    e = np.concatenate([e, np.repeat(np.deg2rad(np.array([-45., 0., 37., 60., 75., 90.])), nodes.size * 3)])
+    z = np.concatenate([z, np.tile(np.concatenate([nodes, nodes + 1e-9, nodes - 1e-9]), 6)])
+    idx_h, w_h = bas.sphere.interpolation_params_batch(e, z, branch="pyfloat")
+    idx_d, w_d = bas.sphere.interpolation_params_device(torch.from_numpy(e).cuda(), torch.from_numpy(z).cuda(),
+                                                        branch="pyfloat")
+    assert np.array_equal(idx_d.cpu().numpy(), idx_h)
+    assert np.array_equal(w_d.cpu().numpy(), w_h)
+    with pytest.raises(ValueError):
+        bas.sphere.interpolation_params_device(torch.zeros(2, dtype=torch.float64).cuda(),
+                                               torch.zeros(2, dtype=torch.float64).cuda(), branch="f32")
+
+
+def test_pyfloat_preset_renders_reference_exact_without_host_calls(tables):
+    """The reference's circle_horizontal lambda returns Python floats: 863 scalar calls reproduce it (round 2); the
+    vectorised call now selects the float32 branch by itself and gives the same bytes - and the reference's golden."""
+    g = golden("render_pyfloat_circle.npz")
+    meta = json.loads(str(g["meta"]))
+    d = _device_table(tables["consistent"].truncated(128))
+    k = 2 * np.pi / (meta["period_s"] * meta["fs"])
+    traj = lambda t: (0, (k * t) % (2 * np.pi))         # noqa: E731  the CLI's lambda form
+    scalar = bas.make_signal_move_2d(g["x"], meta["K"], meta["S"], traj, d)
+    vec = bas.make_signal_move_2d(g["x"], meta["K"], meta["S"], traj, d, vectorized=True)
+    assert np.array_equal(scalar, vec)
+    assert rel_err(vec, g["y"]) <= REL
+    # forcing the other branch moves grid-node decisions: a different (still valid) render
+    f64 = bas.make_signal_move_2d(g["x"], meta["K"], meta["S"], traj, d, vectorized=True, branch="f64")
+    assert not np.array_equal(f64, vec)
+
+
+@pytest.mark.parametrize("name", ["circle_horizontal", "circle_askew", "spiral", "passing", "circle_front"])
+def test_cli_presets_vectorised_equal_scalar(tables, name):
+    """Every preset of the reference's main() (apply_hrtf.py:580-593): the one-call device path equals the per-chunk
+    scalar path on the parameters (bit for bit) for 2 s of audio, whichever branch the preset selects."""
+    import torch
+    from binaural_audio_synthesis_amd import cli
+    fs = 44100
+    traj = cli.presets(fs)[name]
+    branch = bas.apply_hrtf.trajectory_branch(traj)
+    times = np.arange(0, 2 * fs + 512, 512)
+    idx_s = np.array([bas.sphere.interpolation_params(*traj(int(t)))[0] for t in times])
+    w_s = np.array([bas.sphere.interpolation_params(*traj(int(t)))[1] for t in times])
+    e, a = traj(times.astype(np.float64))
+    e, a = np.broadcast_arrays(np.asarray(e, dtype=np.float64), np.asarray(a, dtype=np.float64))
+    idx_d, w_d = bas.sphere.interpolation_params_device(torch.from_numpy(e.copy()).cuda(), torch.from_numpy(a.copy()).cuda(),
+                                                        branch=branch)
+    assert np.array_equal(idx_d.cpu().numpy(), idx_s), name
+    # np.cos / np.sin of an array may differ from the scalar call by an ulp (SIMD loops): the weights may then
+    # differ by that much, the indices never do on these presets
+    assert np.allclose(w_d.cpu().numpy(), w_s, rtol=0, atol=1e-12), name
+
+
+# ---------------------------------------------------------------------------
+# streaming: prepare(), the one-launch epilogue, the end boundary across re-layouts, far trajectories
+# ---------------------------------------------------------------------------
+def _scene(n_src, n, k, seed=40):
+    sigs = np.stack([bas.synth.integer_noise(seed + i, n, 0.1) for i in range(n_src)])
+    t = np.arange(0, n + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        tr = bas.synth.trajectory(("spiral", "circle_askew", "passing")[i % 3], period_s=0.07, length_s=n / 44100, turns=3.0)
+        elev[i], azim[i] = tr(t)
+    return sigs, elev, azim
+
+
+@pytest.mark.parametrize("l,k,s,B,nblocks", [(128, 512, 32, 512, 6), (128, 512, 32, 4096, 3), (100, 32, 32, 32, 9),
+                                             (100, 32, 32, 64, 5), (128, 256, 32, 1024, 3)])
+def test_stream_prepare_then_graph_from_the_first_block(tables, l, k, s, B, nblocks):
+    """prepare(B) captures the block's hipGraph before streaming starts and leaves the carried state alone: the
+    FIRST process() call already replays it (no capture inside the stream), the concatenated blocks equal the
+    whole-signal render, the running peak (now taken by bas_stream_epilogue_f32 over the emitted samples only) equals
+    the whole render's.  (l, k) = (100, 32): the halo (128) is longer than the block - the overlapping carry."""
+    import torch
+    h = tables["consistent"].truncated(l)
+    d = _device_table(h)
+    n_src, n = 3, B * nblocks
+    sigs, elev, azim = _scene(n_src, n, k)
+    whole = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none")
+    st = bas.StreamRenderer(d, n_src, k, s)
+    st.input_view(B)
+    st.prepare(B)
+    g0 = st._graph
+    assert g0 is not None and st.samples_in == 0 and st.peak == 0.0
+    outs = []
+    for b in range(nblocks):
+        c0 = b * B // k
+        outs.append(st.process(sigs[:, b * B:(b + 1) * B], elev[:, c0:c0 + B // k + 1], azim[:, c0:c0 + B // k + 1]))
+        assert st._graph is g0                            # never re-captured while streaming
+    outs.append(st.finish())
+    got = torch.cat(outs, dim=0)
+    assert got.shape == whole.shape
+    assert rel_err(got.cpu().numpy(), whole.cpu().numpy()) <= 1e-6
+    assert abs(st.peak - float(whole.abs().max())) <= 1e-6 * st.peak
+    # and prepare() in the MIDDLE of a stream (a change of block size) keeps the carried state
+    st2 = bas.StreamRenderer(d, n_src, k, s)
+    outs = [st2.process(sigs[:, :B], elev[:, :B // k + 1], azim[:, :B // k + 1])]
+    st2.prepare(2 * B)
+    c0 = B // k
+    outs.append(st2.process(sigs[:, B:3 * B], elev[:, c0:c0 + 2 * B // k + 1], azim[:, c0:c0 + 2 * B // k + 1]))
+    got2 = torch.cat(outs, dim=0)
+    assert rel_err(got2.cpu().numpy(), whole[:3 * B].cpu().numpy()) <= 1e-6
+
+
+def test_stream_finish_after_a_change_of_block_size(tables):
+    """trajectory_views(B') after the last process() re-allocates the per-block angle buffers; the
+    boundary at the stream's end lives in its own buffer now, so finish() still cross-fades towards the right
+    direction (before: towards (0, 0), silently)."""
+    import torch
+    h = tables["consistent"].truncated(128)
+    d = _device_table(h)
+    n_src, k, s, B = 3, 512, 32, 2048
+    sigs, elev, azim = _scene(n_src, 2 * B, k, seed=70)
+    whole = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none")
+    st = bas.StreamRenderer(d, n_src, k, s)
+    outs = []
+    for b in range(2):
+        c0 = b * B // k
+        outs.append(st.process(sigs[:, b * B:(b + 1) * B], elev[:, c0:c0 + B // k + 1], azim[:, c0:c0 + B // k + 1]))
+    st.trajectory_views(4 * B)                            # a producer asks for views of another size, then stops
+    outs.append(st.finish())
+    got = torch.cat(outs, dim=0)
+    assert rel_err(got.cpu().numpy(), whole.cpu().numpy()) <= 1e-6
+
+
+def test_far_end_of_an_hour_long_stream(tables):
+    """BASELINE config 5's LAST block: t ~ 1.7e8 samples, azimuths ~ 1e4 rad (the trajectory keeps winding for an
+    hour).  The wrap `azim % 2 pi` (sphere.py:86) runs in the caller's binary64: the device parameters must equal the
+    host's bit for bit out there, and the rendered block must match the oracle, whose float64 definition wraps the
+    same way."""
+    import torch
+    h = tables["consistent"].truncated(128)
+    d = _device_table(h)
+    n_src, k, s, l, fs, B = 16, 512, 32, 128, 48000, 8192
+    n_blocks_hour = 3600 * fs // 262144                   # bench.py --mode stream: 659 blocks of 262 144
+    t0 = float((n_blocks_hour - 1) * 262144)              # first sample of the last block: ~1.725e8
+    src = np.arange(n_src, dtype=np.float64)[:, None] * 64
+    phase = 2 * math.pi * src / 1024
+    period = (2.0 + (src % 256) / 64.0) * fs
+    t = np.arange(B // k + 1, dtype=np.float64)[None, :] * k + t0
+    elev = (math.pi / 4) * np.cos(2 * math.pi * t / period + phase)
+    azim = 2 * math.pi * t / period + phase
+    assert azim.max() > 1e4 and t.max() > 1.7e8
+    idx_h, w_h = bas.sphere.interpolation_params_batch(elev, azim)
+    idx_d, w_d = bas.sphere.interpolation_params_device(torch.from_numpy(elev).cuda(), torch.from_numpy(azim).cuda())
+    assert np.array_equal(idx_d.cpu().numpy(), idx_h) and np.array_equal(w_d.cpu().numpy(), w_h)
+    for i in range(0, n_src, 5):                          # the oracle's scalar path (reference expressions) agrees
+        for c in (0, 7, B // k):
+            pt, qt, at, pb, qb, ab, a = orc.interp2d_params(np.float64(elev[i, c]), np.float64(azim[i, c]))
+            assert (pt, qt, pb, qb) == tuple(idx_h[i, c]) and (float(at), float(ab), float(a)) == tuple(w_h[i, c])
+    # one block rendered there (the stream's carried state starts as silence; what matters is the angle arithmetic)
+    x = np.stack([bas.synth.integer_noise(900 + i, B, 0.05) for i in range(n_src)])
+    st = bas.StreamRenderer(d, n_src, k, s)
+    y = torch.cat([st.process(x, torch.from_numpy(elev).cuda(), torch.from_numpy(azim).cuda()), st.finish()], dim=0)
+    irs = [np.stack([orc.interp2d(h, elev[i, c], azim[i, c]) for c in range(B // k + 1)]) for i in range(n_src)]
+    want = orc.render_mix(x, k, s, irs, normalize=False)
+    assert y.shape == want.shape and rel_err(y.cpu().numpy(), want) <= REL
+
+
+# ---------------------------------------------------------------------------
+# the RCCL path on the one GPU there is: backend "nccl", world_size 1
+# ---------------------------------------------------------------------------
+def _root():
+    return os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_distributed_paths_under_nccl_world_size_1():
+    """tests/nccl_world1.py in a child process: render_sources_sharded, the async gather + fixed-order sum,
+    render_time_sharded and ShardedStreamRenderer with a real RCCL communicator equal the single-process results
+    bit for bit (every other multi-rank test of this repository runs under gloo)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(_root(), "tests", "nccl_world1.py")], capture_output=True, text=True,
+                       timeout=900, env=_clean_env(), cwd=_root())
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "nccl world_size=1: OK" in r.stdout
+
+
+def test_bench_collective_path_under_nccl_world_size_1():
+    """bench.py --gpus 1 --force-pg: init_process_group("nccl", world_size=1, device_id=...), then the N > 1 step
+    (graph-replayed render, async dist.gather, fixed-order sum on the root, overlapped double-buffered steps, the
+    settle loop's device-side all_reduce).  BAS_BENCH_CHECK=1 makes bench.py assert that the pipelined mix equals
+    the synchronous one and that both equal the plain N = 1 step bit for bit."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--gpus", "1", "--force-pg", "--sources", "6",
+                        "--seconds", "0.5", "--steps", "4", "--warmup", "1", "--settle-ms", "30", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=_clean_env(BAS_BENCH_CHECK="1"), cwd=_root())
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["collective_path"].startswith("nccl world_size=1")
+    assert "hipGraph" in d["graph"] and d["roofline"]["kernel_ms"] > 0
+    assert "check: pipelined mix == synchronous mix" in r.stderr
+    assert "check: collective path at world_size 1 == plain step, bit for bit" in r.stderr
+    assert d["self_check_rel_err"] <= 1e-5
+
+
+def test_bench_line_round3_fields():
+    """The N = 1 line: cold figure, executed-flop fraction, oracle self check of the TIMED path, CPU baseline taken
+    before the first GPU call (its pool cannot have been forked from a process that holds the GPU)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--sources", "4", "--seconds", "0.5", "--steps", "2",
+                        "--warmup", "1", "--settle-ms", "20", "--cpu-sources-per-core", "1"], capture_output=True, text=True,
+                       timeout=600, env=_clean_env(BAS_BENCH_MAX_CORES="2"), cwd=_root())
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert d["cold"]["ms_per_step"] > 0 and d["graph"] == "plain launches"
+    assert 0 < d["valu"]["frac_executed"] < d["valu"]["frac"] < 1
+    assert d["self_check_rel_err"] <= 1e-5 and "multi_gpu_status" in d
+    assert d["cpu_baseline"]["cores"] == 2 and d["roofline"]["bound"] == "hbm"
+    # the stored-IR ablation through an S = 8 scene: no fast FIR there, so no executed-flop claim
+    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--sources", "4", "--seconds", "0.5", "--steps", "2",
+                        "--warmup", "1", "--settle-ms", "0", "--subchunk", "8", "--no-cpu-baseline"], capture_output=True,
+                       text=True, timeout=600, env=_clean_env(), cwd=_root())
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    assert "executed" not in d["valu"] and d["config"]["fused"] is False
+
+
+def test_bench_stream_line_has_a_roofline():
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--mode", "stream", "--sources", "16", "--fs", "48000",
+                        "--block", "16384", "--steps", "4", "--warmup", "1"], capture_output=True, text=True, timeout=600,
+                       env=_clean_env(), cwd=_root())
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["kernel_ms"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert d["ps_per_source_sample"] > 0 and d["value"] > 0

@@ -62,7 +62,7 @@ def test_library_exports_every_declared_symbol():
     lib = bas._hip.lib()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.bas_version() == 2
+    assert lib.bas_version() == bas._hip.ABI_VERSION
     assert lib.bas_last_error() == b""
 
 
@@ -109,7 +109,7 @@ def test_diagnostic_build_is_separate_and_only_it_reads_the_environment():
     """libbas_hip_diag.so (-DBAS_DIAG) exports the same ABI; the shipped library contains neither hook string."""
     hip = bas._hip
     with hip.use_library(hip.DIAG_LIB_PATH) as diag:
-        assert hip.lib() is diag and diag.bas_version() == 2
+        assert hip.lib() is diag and diag.bas_version() == hip.ABI_VERSION
     assert hip.lib() is not diag
     shipped = open(hip.LIB_PATH, "rb").read()
     assert b"BAS_FORCE_KERNEL" not in shipped and b"BAS_DEBUG_FLAGS" not in shipped

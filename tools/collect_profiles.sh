@@ -19,12 +19,12 @@ done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_SQ -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_SQ.err
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_SQ2 -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_SQ2.err
 # 4. unfused path for comparison (interp2d + hd kernel), same box
-BAS_BENCH_FUSED=0 $B --steps 300 --warmup 10 --no-cpu-baseline > $O/bench_unfused.json 2> $O/bench_unfused.err
-BAS_BENCH_FUSED=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_unfused -o bench -- python3 bench.py --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/prof_unfused.err
+$B --unfused --steps 300 --warmup 10 --no-cpu-baseline > $O/bench_unfused.json 2> $O/bench_unfused.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_unfused -o bench -- python3 bench.py --unfused --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/prof_unfused.err
 # 5. single source (BASELINE configs 2 / 3)
 $B --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > $O/single_source.json 2> $O/single.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o bench -- python3 bench.py --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > /dev/null 2>> $O/single.err
-BAS_LIB_PATH=$PWD/binaural-audio-synthesis_amd/csrc/libbas_hip_diag.so BAS_FZ_NW=4 $B --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > $O/single_source_tile8192.json 2>> $O/single.err
+BAS_FZ_NW=4 $B --lib $PWD/binaural-audio-synthesis_amd/csrc/libbas_hip_diag.so --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > $O/single_source_tile8192.json 2>> $O/single.err
 python3 tools/single_source_latency.py > $O/single_source_latency.txt 2>&1
 # 6. streaming: config 5 shape, and host time of real-time sized blocks
 $B --mode stream --sources 1024 --fs 48000 --steps 20 --warmup 3 > $O/stream_1024src_48k.json 2> $O/stream.err
