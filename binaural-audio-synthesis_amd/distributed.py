@@ -182,8 +182,11 @@ class ShardedStreamRenderer:
         self.local = stream_factory(tbl, len(self.sources), chunksize, subchunksize)
         self.group, self.dst, self.mix_fn = group, dst, mix_fn
         self._peak = None
+        self._solo = not dist.is_initialized() and mix_fn is None     # no process group: the local stream IS the mix
 
     def _combine(self, out_local):
+        if self._solo:
+            return out_local
         res = gather_mix(out_local.t(), group=self.group, dst=self.dst, mix_fn=self.mix_fn, normalize="none",
                          return_peak=True)
         if res is None:
@@ -201,4 +204,6 @@ class ShardedStreamRenderer:
 
     @property
     def peak(self):
+        if self._solo:
+            return self.local.peak
         return None if self._peak is None else float(self._peak.reshape(-1)[0])
