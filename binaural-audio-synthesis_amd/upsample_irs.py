@@ -7,10 +7,15 @@ MATLAB-v5 struct `irs_and_delaydiffs` with the five fields apply_hrtf.py:38-44 i
 
 PARITY UNPINNED.  Octave is not available in the build container and the IRCAM LISTEN data
 (upsample_irs.m:1) cannot be fetched, so nothing here is checked against the reference's output.  The
-band-limited resampler is scipy.signal.resample_poly with a Kaiser (beta = 5) window, the design family
-Octave's `resample` uses; its coefficients are not guaranteed to match Octave's.  What IS tested
-(tests/test_upsample_irs.py): antisymmetry and zero diagonal of the delay matrices, exact known answers
-for shifted impulses, and that the written file loads through load_irs_and_delaydiffs's indexing.
+band-limited resampler `octave_resample` restates the algorithm of `resample` in the Octave Forge signal
+package (the function upsample_irs.m:37-44, :66 calls; resample.m by E. Chassande-Mottin) step by step -
+filter design, zero padding, upfirdn, group-delay trim - from the published algorithm as the builder
+remembers it: the package is not installed here and cannot be fetched, so neither its source lines nor its
+output could be compared (MATLAB's `resample` is a different design: firls with Kaiser beta 5 and
+half-length 10 max(p, q)).  What IS tested (tests/test_upsample_irs.py): known answers of the resampler
+(length, exact interpolation of the input samples, DC gain, a band-limited sinusoid, the filter's published
+parameters), antisymmetry and zero diagonal of the delay matrices, exact known answers for shifted
+impulses, and that the written file loads through load_irs_and_delaydiffs's indexing.
 
 This is an offline, run-once precompute on the host (17 391 pairs x 2 ears of 512-tap correlations, batched
 per row of the pair matrix through FFTs); it is not part of the render path and has no GPU kernel.
@@ -20,32 +25,82 @@ import numpy as np
 
 def parabolic_interpolation(vec):
     """Abscissa of the vertex of the parabola through (-1, vec[0]), (0, vec[1]), (1, vec[2])
-    (upsample_irs.m:88-101).  vec[1] must be the maximum."""
+    (upsample_irs.m:88-101).  vec[1] must be the maximum as Octave's `max` finds it (:92-93: the FIRST
+    largest element, so a tie with vec[0] is rejected); ValueError otherwise (the reference asserts)."""
     vec = np.asarray(vec, dtype=np.float64)
-    assert vec.shape == (3,)
-    assert int(np.argmax(vec)) == 1
+    if vec.shape != (3,):
+        raise ValueError("parabolic_interpolation: need three points")           # :91
+    if int(np.argmax(vec)) != 1:
+        raise ValueError("parabolic_interpolation: the middle point is not the (first) maximum")   # :92-93
     c = vec[1]
     a = 0.5 * (vec[0] + vec[2] - 2 * c)
     b = 0.5 * (vec[2] - vec[0])
-    assert a != 0
+    if a == 0:
+        raise ValueError("parabolic_interpolation: three collinear points")      # :98
     return -b / (2 * a)
 
 
-def _resample(x, upsampling):
+def octave_resample_filter(p, q):
+    """The anti-aliasing / interpolation filter Octave's signal-package `resample(x, p, q)` designs when none is
+    given: a Kaiser-windowed ideal low-pass.
+        stop-band rejection 60 dB (log10_rejection = -3)       cutoff f_c = 1 / (2 max(p, q)) cycles per sample
+        roll-off width f_c / 10                                  half-length L = ceil((60 - 8) / (28.714 * width))
+        ideal filter  2 p f_c sinc(2 f_c t), t = -L .. L         Kaiser beta = 0.1102 (60 - 8.7) = 5.653  (rejection > 50 dB)
+    (the two empirical formulas are Proakis & Manolakis, Digital Signal Processing, eqs. 7.62 / 7.63, which the
+    package cites).  p = 8, q = 1: L = 290, 581 taps.  Returns (h, L)."""
+    p, q = int(p), int(q)
+    g = int(np.gcd(p, q))
+    p, q = p // g, q // g
+    rejection_db = 60.0
+    fc = 1.0 / (2.0 * max(p, q))
+    width = fc / 10.0
+    L = int(np.ceil((rejection_db - 8.0) / (28.714 * width)))
+    t = np.arange(-L, L + 1, dtype=np.float64)
+    ideal = 2.0 * p * fc * np.sinc(2.0 * fc * t)
+    beta = 0.1102 * (rejection_db - 8.7)
+    return np.kaiser(2 * L + 1, beta) * ideal, L
+
+
+def octave_resample(x, p, q=1, axis=-1):
+    """`resample(x, p, q)` of the Octave signal package along `axis`: zero-stuff by p, filter with
+    octave_resample_filter, keep every q-th sample, and trim the filter's group delay so that output sample j sits at
+    input time j q / p.  Output length ceil(Lx p / q) exactly (upsample_irs.m:37-44 relies on 512 U).
+    Steps as the package performs them: pad the filter in front with nz_pre = floor(q - mod(L, q)) zeros, offset =
+    floor((L + nz_pre) / q), y = upfirdn(x, h_padded, p, q)[offset : offset + Ly] (samples the filter tail would
+    supply beyond the data are zeros)."""
     import scipy.signal
-    return scipy.signal.resample_poly(np.asarray(x, dtype=np.float64), upsampling, 1, window=("kaiser", 5.0))
+    x = np.moveaxis(np.asarray(x, dtype=np.float64), axis, -1)
+    p, q = int(p), int(q)
+    g = int(np.gcd(p, q))
+    p, q = p // g, q // g
+    h, L = octave_resample_filter(p, q)
+    lx = x.shape[-1]
+    ly = int(np.ceil(lx * p / q))
+    nz_pre = int(np.floor(q - np.mod(L, q)))
+    hpad = np.concatenate([np.zeros(nz_pre), h])
+    offset = int(np.floor((L + nz_pre) / q))
+    full = scipy.signal.upfirdn(hpad, x, up=p, down=q, axis=-1)
+    if full.shape[-1] < offset + ly:                          # (the package extends the filter with zeros instead)
+        full = np.concatenate([full, np.zeros(full.shape[:-1] + (offset + ly - full.shape[-1],))], axis=-1)
+    return np.moveaxis(full[..., offset:offset + ly], -1, axis)
+
+
+def _resample(x, upsampling, axis=-1):
+    return octave_resample(x, upsampling, 1, axis=axis)
 
 
 def delaydifference(signal_a, signal_b, upsampling):
     """Delay of b relative to a in (non-upsampled) samples, > 0 if b comes after a (upsample_irs.m:58-77)."""
     a = np.asarray(signal_a, dtype=np.float64).ravel()
     b = np.asarray(signal_b, dtype=np.float64).ravel()
-    assert a.size == b.size
+    if a.size != b.size:
+        raise ValueError("delaydifference: signals of different length")     # :62
     n = a.size
     xc = np.convolve(a[::-1], b)                             # cross-correlation, length 2n-1 (:66)
     xc_up = _resample(xc, upsampling)
-    k = int(np.argmax(xc_up))                                # 0-based peak (:69)
-    k = min(max(k, 1), xc_up.size - 2)
+    k = int(np.argmax(xc_up))                                # 0-based peak (:69; first maximum, like Octave's max)
+    if k < 1 or k > xc_up.size - 2:
+        raise ValueError("delaydifference: cross-correlation peak at the edge of its support")   # (:70 indexes out of range)
     peak = k + parabolic_interpolation(xc_up[k - 1:k + 2])   # (:70), 0-based
     return peak / upsampling - (n - 1)                       # (:73-76) in 0-based indexing
 
@@ -62,15 +117,20 @@ def delaydifferences_from(h, i, upsampling):
     if others.shape[0] == 0:
         return np.zeros((0,))
     xc = scipy.signal.fftconvolve(np.broadcast_to(h[i, ::-1], others.shape), others, axes=1)   # (m, 2n-1)
-    xc_up = scipy.signal.resample_poly(xc, upsampling, 1, axis=1, window=("kaiser", 5.0))
-    k = np.clip(np.argmax(xc_up, axis=1), 1, xc_up.shape[1] - 2)
+    xc_up = _resample(xc, upsampling, axis=1)
+    k = np.argmax(xc_up, axis=1)                             # first maximum of every row, like Octave's max (:69)
+    if np.any(k < 1) or np.any(k > xc_up.shape[1] - 2):
+        raise ValueError("delaydifferences_from: cross-correlation peak at the edge of its support")
     rows = np.arange(xc_up.shape[0])
     lo, mid, hi = xc_up[rows, k - 1], xc_up[rows, k], xc_up[rows, k + 1]
-    # the reference's preconditions (upsample_irs.m:90-98): the middle sample is the maximum, the parabola is not flat
-    assert np.all(mid >= lo) and np.all(mid >= hi), "cross-correlation peak at the edge of its support"
+    # the reference's preconditions (upsample_irs.m:90-98): the middle sample is the first maximum (a tie with the
+    # sample before it is rejected), the parabola is not flat - exceptions, not asserts: they must survive python -O
+    if not (np.all(mid > lo) and np.all(mid >= hi)):
+        raise ValueError("delaydifferences_from: the middle point is not the (first) maximum")
     a = 0.5 * (lo + hi - 2 * mid)
     b = 0.5 * (hi - lo)
-    assert np.all(a != 0), "three collinear points around a cross-correlation peak"
+    if np.any(a == 0):
+        raise ValueError("delaydifferences_from: three collinear points around a cross-correlation peak")
     peak = k - b / (2 * a)
     return peak / upsampling - (n - 1)
 
@@ -82,7 +142,8 @@ def upsample_irs(hrirs_left, hrirs_right, upsampling=8, progress=None):
     import scipy.signal
     hl = np.asarray(hrirs_left, dtype=np.float64)
     hr = np.asarray(hrirs_right, dtype=np.float64)
-    assert hl.shape == hr.shape and hl.ndim == 2
+    if hl.shape != hr.shape or hl.ndim != 2:
+        raise ValueError("upsample_irs: need two (n_dir, n_taps) arrays of equal shape")
     n_dir, n_taps = hl.shape
     dl = np.zeros((n_dir, n_dir))
     dr = np.zeros((n_dir, n_dir))
@@ -93,9 +154,10 @@ def upsample_irs(hrirs_left, hrirs_right, upsampling=8, progress=None):
             progress(i, n_dir)
     dl = dl - dl.T                                           # antisymmetry (:31-32)
     dr = dr - dr.T
-    irs_left = scipy.signal.resample_poly(hl, upsampling, 1, axis=1, window=("kaiser", 5.0))     # (:37-44)
-    irs_right = scipy.signal.resample_poly(hr, upsampling, 1, axis=1, window=("kaiser", 5.0))
-    assert irs_left.shape == (n_dir, n_taps * upsampling)
+    irs_left = _resample(hl, upsampling, axis=1)             # (:37-44)
+    irs_right = _resample(hr, upsampling, axis=1)
+    if irs_left.shape != (n_dir, n_taps * upsampling):
+        raise ValueError("upsample_irs: resampled length is not n_taps * upsampling")
     return {"upsampling": float(upsampling), "diffs_left": dl, "diffs_right": dr,
             "irs_left": irs_left, "irs_right": irs_right}
 

@@ -19,8 +19,62 @@ def test_parabolic_interpolation_known_answers():
     x0 = 0.3
     f = lambda x: 5.0 - 2.0 * (x - x0) ** 2                  # noqa: E731
     assert up.parabolic_interpolation([f(-1), f(0), f(1)]) == pytest.approx(x0, abs=1e-12)
-    with pytest.raises(AssertionError):
+    with pytest.raises(ValueError):
         up.parabolic_interpolation([3.0, 2.0, 1.0])
+    with pytest.raises(ValueError):                          # Octave's max returns the FIRST largest element (:92-93)
+        up.parabolic_interpolation([2.0, 2.0, 1.0])
+    assert up.parabolic_interpolation([1.0, 2.0, 2.0]) == pytest.approx(0.5)   # a tie with the LAST point passes there too
+    with pytest.raises(ValueError):
+        up.parabolic_interpolation([2.0, 2.0, 2.0])
+
+
+def test_octave_resample_filter_parameters():
+    """The published design of the signal package's resample for p = 8, q = 1: 60 dB rejection, cutoff 1/16,
+    roll-off 1/160 -> half-length ceil(52 / (28.714 / 160)) = 290 (581 taps), Kaiser beta 0.1102 (60 - 8.7)."""
+    h, L = up.octave_resample_filter(8, 1)
+    assert L == 290 and h.size == 581
+    assert np.array_equal(h, h[::-1])                        # linear phase
+    assert h[L] == pytest.approx(1.0, abs=1e-15)             # 2 p f_c sinc(0) = 1: input samples pass unchanged
+    assert np.allclose(h[L + 8::8], 0.0, atol=1e-15)         # and every other multiple of p is a zero of the sinc
+    beta = 0.1102 * (60 - 8.7)
+    assert np.allclose(h, np.kaiser(581, beta) * np.sinc(np.arange(-290, 291) / 8.0), atol=1e-15)
+    assert h.sum() == pytest.approx(8.0, rel=2e-3)           # pass-band gain p: unit gain per output phase
+    h32, L32 = up.octave_resample_filter(3, 2)
+    assert L32 == int(np.ceil(52 / (28.714 * (1 / 6) / 10)))
+    h2, _ = up.octave_resample_filter(16, 2)                 # common factors are removed first
+    assert np.array_equal(h2, h)
+
+
+@pytest.mark.parametrize("p", [2, 8])
+def test_octave_resample_known_answers(p):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(512)
+    y = up.octave_resample(x, p, 1)
+    assert y.shape == (512 * p,)                             # upsample_irs.m:37-44 relies on exactly 512 U
+    assert np.allclose(y[::p], x, rtol=0, atol=1e-14)        # interpolation: the input samples are kept exactly
+    # DC: away from the ends (half-length 290 / 8 ~ 36 input samples at p = 8) a constant stays a constant to the
+    # pass-band ripple of a 60 dB design
+    c = up.octave_resample(np.ones(400), p, 1)
+    m = 40 * p
+    assert np.allclose(c[m:-m], 1.0, atol=2e-3)
+    # a band-limited sinusoid well inside the pass band comes out as the same sinusoid on the fine grid
+    f = 0.11
+    n = np.arange(600)
+    s = up.octave_resample(np.sin(2 * np.pi * f * n + 0.4), p, 1)
+    fine = np.sin(2 * np.pi * f * np.arange(600 * p) / p + 0.4)
+    assert np.abs(s[m:-m] - fine[m:-m]).max() < 3e-3
+    # above the cutoff of the ORIGINAL rate nothing can exist: a 0.45 cycles/sample tone is still reproduced (it is
+    # below 0.5), its image at (1 - 0.45) / p cycles per fine sample is rejected by ~60 dB
+    tone = up.octave_resample(np.cos(2 * np.pi * 0.45 * n), p, 1)[m:-m]
+    spec = np.abs(np.fft.rfft(tone * np.hanning(tone.size)))
+    freqs = np.fft.rfftfreq(tone.size)
+    image = spec[np.abs(freqs - (1 - 0.45) / p) < 0.004].max()
+    main = spec[np.abs(freqs - 0.45 / p) < 0.004].max()
+    assert image < 4e-3 * main
+    # batched along an axis == row by row; rational factors give ceil(Lx p / q) samples
+    xb = rng.standard_normal((3, 100))
+    assert np.array_equal(up.octave_resample(xb, p, 1, axis=1), np.stack([up.octave_resample(r, p, 1) for r in xb]))
+    assert up.octave_resample(np.ones(101), 3, 2).shape == (152,)
 
 
 @pytest.mark.parametrize("shift", [0.0, 1.0, -3.0, 2.5, -0.375, 7.125])
@@ -63,8 +117,10 @@ def test_batched_rows_equal_the_per_pair_function():
         got = up.delaydifferences_from(h, i, 8)
         want = np.array([up.delaydifference(h[i], h[j], 8) for j in range(i + 1, n_dir)])
         assert got.shape == want.shape and np.allclose(got, want, rtol=0, atol=1e-9)
-    with pytest.raises(AssertionError):                      # a flat correlation has no strict peak: a == 0 (:97)
+    with pytest.raises(ValueError):                          # a flat correlation has no strict peak (:92-98)
         up.delaydifferences_from(np.zeros((2, 16)), 0, 8)
+    with pytest.raises(ValueError):
+        up.delaydifference(np.zeros(16), np.zeros(17), 8)
 
 
 def test_full_size_table_builds_quickly():
