@@ -233,12 +233,28 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     int geo_sg = -1;
     int seg0 = 0, Lseg = 0, halo = 0, nrows = 0, c0 = 0, mo0 = 0;
     long xbase = 0;
-    // this wave's share of the chunk slots: [slot_a, slot_b), evaluating chunk IRs slot_a .. slot_b
-    // (HONLY: rows [slot_a, slot_b) of the nslots + 1 rows, one chunk IR each)
+    // this wave's share of the chunk IRs.  HONLY: rows [slot_a, slot_b) of the nslots + 1 (h_L, h_R) rows, one chunk IR
+    // each.  (h0, d) slots: the nslots + 1 chunk IRs are dealt in balanced contiguous ranges [slot_a, slot_b) - 5, 5, 4, 4
+    // for the 18 IRs under a tile of 8192 at K = 512 - and a wave writes the slots [slot_a, slot_b): slot i holds
+    // (IR i, IR i+1 - IR i), so its LAST slot needs the FIRST IR of the next wave, which that wave leaves in LDS as soon
+    // as it has it (bnd / flags below; no IR is evaluated twice: 18 per pass where round 2 evaluated 21, and the
+    // longest chain a wave evaluates is 5 IRs instead of 6).
     const int nrows_h = A.nslots + (HONLY ? 1 : 0);
-    const int slot_a = wv * A.spw;
-    const int slot_b = slot_a + A.spw < nrows_h ? slot_a + A.spw : nrows_h;
-    const int n_ev = slot_a < nrows_h ? slot_b - slot_a + (HONLY ? 0 : 1) : 0;   // chunk IRs this wave evaluates per pass
+    int slot_a, slot_b;
+    if (HONLY) {
+        slot_a = wv * A.spw;
+        slot_b = slot_a + A.spw < nrows_h ? slot_a + A.spw : nrows_h;
+    } else {
+        const int n_ir = A.nslots + 1, base = n_ir / NW, rem = n_ir - base * NW;
+        slot_a = wv * base + (wv < rem ? wv : rem);
+        slot_b = slot_a + base + (wv < rem ? 1 : 0);
+    }
+#ifdef FZ_NO_EVAL          // ablation (never shipped): no chunk-IR evaluation at all - the FIR runs on whatever the LDS holds
+    const int n_ev = 0;
+#else
+    const int n_ev = slot_a < slot_b ? slot_b - slot_a : 0;      // chunk IRs this wave evaluates per pass
+#endif
+    const bool need_next = !HONLY && NW > 1 && n_ev > 0 && slot_b <= A.nslots;   // slot slot_b - 1 exists: it needs IR slot_b
 
 #if FZ_START_DELAY
     // The two workgroups of a CU alternate between a latency-bound staging phase and a VALU-bound FIR phase.
@@ -255,6 +271,11 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long st_begin = __builtin_amdgcn_s_memrealtime();
 #endif
+    if constexpr (!HONLY && NW > 1) {                        // hand-over flags of the boundary IRs: no pass has id 0
+        f32x4 *pl_base0 = reinterpret_cast<f32x4 *>(hd + ((nrows_h * SLOTF + 3) & ~3));
+        unsigned *flags0 = reinterpret_cast<unsigned *>(pl_base0 + NW * (MAXEV * PL4) + NW * 64);
+        if (tid < NW) flags0[tid] = 0u;                      // (ordered before their first use by the first pass's barrier)
+    }
     for (long pid = 0; pid < n_pass; ++pid) {
         FZ_STAMP_NW(t0);
         if (tile != geo_tile || sg != geo_sg) {
@@ -315,8 +336,11 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
 
         // ---- registers -> LDS: plans into this wave's own region, the x window as a column-major image
         // (NW = 1: the plans overlay the last chunk slot, which this wave writes only after its last plan read)
-        f32x4 *plw = NW == 1 ? reinterpret_cast<f32x4 *>(hd + (A.nslots - 1) * HD_SLOT)
-                             : reinterpret_cast<f32x4 *>(hd + ((nrows_h * SLOTF + 3) & ~3)) + wv * (MAXEV * PL4);
+        f32x4 *pl_base = reinterpret_cast<f32x4 *>(hd + ((nrows_h * SLOTF + 3) & ~3));
+        f32x4 *plw = NW == 1 ? reinterpret_cast<f32x4 *>(hd + (A.nslots - 1) * HD_SLOT) : pl_base + wv * (MAXEV * PL4);
+        f32x4 *bnd = pl_base + NW * (MAXEV * PL4);                       // [NW][64]: a wave's first chunk IR, lane-linear
+        volatile unsigned *flags = reinterpret_cast<volatile unsigned *>(bnd + NW * 64);   // [NW]: pass id of bnd[w]
+        const unsigned pass_id = (unsigned)pid + 1u;
 #pragma unroll
         for (int r = 0; r < NPV; ++r)
             if (lane + 64 * r < n_ev * PL4) plw[lane + 64 * r] = pv[r];
@@ -368,18 +392,41 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                     }
                     dst_h += HO_SLOT / 2;
                 } else {
-                    // slot i - 1 = (IR i-1, IR i - IR i-1); iteration 0 writes scrap into slot 0, iteration 1 replaces it
+                    if (NW > 1 && i == 0 && wv > 0) {        // (uniform) the previous wave's last slot needs this IR
+                        bnd[wv * 64 + lane] = h;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) flags[wv] = pass_id;
+                    }
+                    // slot slot_a + i - 1 = (IR i-1, IR i - IR i-1), written once IR i is known
+                    if (i > 0) {
+                        f32x2 h0a, h0b, da, db;
+                        fz_pair_ears(prev, h0a, h0b);
+                        fz_pair_ears(h - prev, da, db);
+                        if (tq < Lseg) {
+                            dst[0] = f32x4{h0a.x, h0a.y, da.x, da.y};
+                            dst[1] = f32x4{h0b.x, h0b.y, db.x, db.y};
+                        }
+                        dst += HD_SLOT / 4;
+                    }
+                    prev = h;
+                }
+                pl = pl_next;
+            }
+            if constexpr (!HONLY && NW > 1) {
+                if (need_next) {                             // (uniform) IR slot_b comes from the next wave's LDS copy
+                    int spins = 0;                           // it stored that IR first thing: normally already there
+                    while (__builtin_amdgcn_readfirstlane(flags[wv + 1]) != pass_id && ++spins < (1 << 22))
+                        __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    const f32x4 nx = bnd[(wv + 1) * 64 + lane];
                     f32x2 h0a, h0b, da, db;
                     fz_pair_ears(prev, h0a, h0b);
-                    fz_pair_ears(h - prev, da, db);
+                    fz_pair_ears(nx - prev, da, db);
                     if (tq < Lseg) {
                         dst[0] = f32x4{h0a.x, h0a.y, da.x, da.y};
                         dst[1] = f32x4{h0b.x, h0b.y, db.x, db.y};
                     }
-                    if (i > 0) dst += HD_SLOT / 4;
-                    prev = h;
                 }
-                pl = pl_next;
             }
         }
         FZ_STAMP(t4);
@@ -575,11 +622,13 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         const long n_tiles_nw = (T_out + 2048L * nw - 1) / (2048L * nw);
         const int nslots = fz_slots_exact(nw, K, (L + 7) & ~7, n_tiles_nw);
         const int maxev = nw == 4 ? 6 : 7;
-        const int spw = (nslots + nw - 1) / nw;
-        if (spw + 1 > maxev) continue;
+        const int spw = (nslots + nw - 1) / nw;                 // (h-only rows only; the (h0, d) path deals nslots + 1 IRs)
+        if ((nslots + 1 + nw - 1) / nw > maxev) continue;
         const int rows = 2048 * nw / 32 + HD_HALO;
         // (one-wave workgroups keep their plans in the LAST slot's space: that slot is written after the last plan read)
-        const size_t lds = (size_t)(8 * (rows + 1) * 4 + ((nslots * HD_SLOT + 3) & ~3) + (nw == 1 ? 0 : nw * maxev * 2 * BAS_PLANS_WORDS)) * sizeof(float);
+        // (+ for nw > 1: one 1 KB boundary chunk IR per wave and the hand-over flags)
+        const size_t lds = (size_t)(8 * (rows + 1) * 4 + ((nslots * HD_SLOT + 3) & ~3) +
+                                    (nw == 1 ? 0 : nw * maxev * 2 * BAS_PLANS_WORDS + nw * 64 * 4 + 4)) * sizeof(float);
         long wg_per_cu = (long)(160 * 1024 / lds);
         const long by_waves = 8 / nw;                        // two waves per SIMD (register budget of the row step)
         if (wg_per_cu > by_waves) wg_per_cu = by_waves;
