@@ -38,6 +38,8 @@ SIGNATURES = {
                                              _c_void_p, _c_void_p, _c_void_p]),
     "bas_interp2d_plan_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_int, _c_int, _c_int,
                                        _c_void_p, _c_size_t, _c_void_p]),
+    "bas_interp2d_plan_angles_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                                              _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "bas_render_fused_supported": (_c_int, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_fused_workspace_bytes": (_c_size_t, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_mix_fused_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_long, _c_int,

@@ -262,7 +262,7 @@ def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=Non
 
 @_hip.on_device_of("x")
 def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix", out=None, events=None,
-                         ws=None, ws_plans=None, fused=None):
+                         ws=None, ws_plans=None, fused=None, angles=None, n_queries=None):
     """interpolate_2d + render for precomputed parameters: x [n_src, T_in] device float32,
     idx int32 [n_src*(n_chunks+1), 4], w float64 [.., 3] on the device.  Uses the fused kernel
     (chunk IRs evaluated inside the FIR kernel, never stored) when the sizes allow it, else
@@ -275,8 +275,11 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     if fused is None or fused:                                # default: fused wherever the kernel serves the shape
         fused = bool(lib.bas_render_fused_supported(n_src, t_in, chunksize, subchunksize, tbl.L)) and \
             tbl.upsampling >= 4 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
-    n_q = idx.shape[0]
+    n_q = idx.shape[0] if idx is not None else n_queries
     if not fused:
+        if idx is None:                                       # (angles given, shape not served by the fused kernel)
+            idx, w = sphere.interpolation_params_device(angles[0], angles[1], branch=angles[2])
+            idx, w = idx.reshape(-1, 4), w.reshape(-1, 3)
         H = interpolate_2d_params(tbl, idx, w, validate=False, ws=ws_plans)
         return render_device(x, chunksize, subchunksize, H.view(n_src, n_q // max(n_src, 1), 2, tbl.L), tbl.L,
                              normalize, out=out, events=events, ws=ws)
@@ -290,8 +293,15 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     if ws is None or ws.numel() < wb:
         ws = torch.empty((wb,), dtype=torch.uint8, device=dev)
     stream = _hip.current_stream(dev)
-    _hip.call("bas_interp2d_plan_f32", _hip.ptr(tbl.diffs), _hip.ptr(idx), _hip.ptr(w), n_q, tbl.ndir, tbl.L,
-              tbl.upsampling, _hip.ptr(ws_plans), ws_plans.numel(), stream)
+    if angles is None:
+        _hip.call("bas_interp2d_plan_f32", _hip.ptr(tbl.diffs), _hip.ptr(idx), _hip.ptr(w), n_q, tbl.ndir, tbl.L,
+                  tbl.upsampling, _hip.ptr(ws_plans), ws_plans.numel(), stream)
+    else:                                                     # small batch: a3 + plans in one launch
+        e, z, branch = angles
+        ring_elev, ring_start, ring_count = sphere._ring_args()
+        _hip.call("bas_interp2d_plan_angles_f32", _hip.ptr(tbl.diffs), _hip.ptr(e), _hip.ptr(z), n_q, ring_elev,
+                  ring_start, ring_count, _hip.ptr(sphere.device_nodes(dev)), sphere.BRANCHES[branch], tbl.ndir, tbl.L,
+                  tbl.upsampling, _hip.ptr(ws_plans), ws_plans.numel(), stream)
     ev = events if events is not None else (None, None)
     _hip.call("bas_render_mix_fused_f32", _hip.ptr(x), x.stride(0), _hip.ptr(tbl.packed), _hip.ptr(ws_plans), n_src,
               t_in, chunksize, subchunksize, tbl.L, tbl.upsampling, tbl.ndir, _hip.ptr(y), 0, _hip.ptr(peak),
@@ -303,8 +313,11 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     return y, peak
 
 
+MERGED_A3_MAX_QUERIES = 65536       # below this a3 rides inside the plan kernel (one launch less; see bas.h)
+
+
 def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize="mix", out=None, events=None,
-                         ws=None, ws_plans=None, fused=None, params=None):
+                         ws=None, ws_plans=None, fused=None, params=None, branch="f64"):
     """The whole device side of make_signal_move_2d for trajectories that live on the GPU: x [n_src, T_in] device
     float32 (T_in % K == 0), elev / azim float64 device tensors [n_src, T_in/K + 1] (radians at t = 0, K, .., T_in).
     bas_traj_params_f64 (a3 + the elevation bracket), then render_params_device (read plans + fused FIR where the
@@ -316,7 +329,15 @@ def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize=
     n_src, t_in = x.shape
     if elev.numel() != n_src * (t_in // chunksize + 1) or azim.numel() != elev.numel():
         raise ValueError("elev/azim must hold one angle per source and chunk boundary")
-    idx, w = sphere.interpolation_params_device(elev, azim, out=params)
+    import torch
+    if not (elev.is_cuda and azim.is_cuda and elev.dtype == torch.float64 and azim.dtype == torch.float64):
+        raise ValueError("elev/azim must be float64 device tensors")
+    if elev.numel() <= MERGED_A3_MAX_QUERIES and elev.is_contiguous() and azim.is_contiguous():
+        if branch not in sphere.BRANCHES:
+            raise ValueError("branch must be 'f64' or 'pyfloat'")
+        return render_params_device(x, chunksize, subchunksize, tbl, None, None, normalize, out=out, events=events, ws=ws,
+                                    ws_plans=ws_plans, fused=fused, angles=(elev, azim, branch), n_queries=elev.numel())
+    idx, w = sphere.interpolation_params_device(elev, azim, out=params, branch=branch)
     return render_params_device(x, chunksize, subchunksize, tbl, idx.reshape(-1, 4), w.reshape(-1, 3), normalize,
                                 out=out, events=events, ws=ws, ws_plans=ws_plans, fused=fused)
 
@@ -415,7 +436,6 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
         if not (np.isfinite(e).all() and np.isfinite(a).all()):
             raise ValueError("trajectory contains non-finite angles")
         ea = torch.from_numpy(np.stack([e, a])).to(dev)                      # one H2D copy for both
-        idx_t, w_t = sphere.interpolation_params_device(ea[0], ea[1], branch=branch)
     else:
         idx = np.empty((len(times), 4), dtype=np.int32)
         w = np.empty((len(times), 3), dtype=np.float64)
@@ -427,7 +447,11 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     x = padded_rows(1, in_length, dev)                                       # :405-406
     src = in_signal if is_tensor else torch.from_numpy(np.ascontiguousarray(in_signal))
     x[0, :n] = src.to(device=dev, dtype=torch.float32)
-    y, _ = render_params_device(x, int(chunksize), int(subchunksize), tbl, idx_t.reshape(-1, 4), w_t.reshape(-1, 3), "mix")
+    if vectorized:
+        y, _ = render_angles_device(x, int(chunksize), int(subchunksize), tbl, ea[0].reshape(1, -1), ea[1].reshape(1, -1),
+                                    "mix", branch=branch)
+    else:
+        y, _ = render_params_device(x, int(chunksize), int(subchunksize), tbl, idx_t.reshape(-1, 4), w_t.reshape(-1, 3), "mix")
     if verbose:
         print(' 100.0%      ')
     out = y.t()                                                              # (out_length, 2), F-ordered like :459

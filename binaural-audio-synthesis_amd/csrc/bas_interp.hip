@@ -182,22 +182,100 @@ __device__ __forceinline__ void ring_plan(RingPlan &rp, const double *__restrict
 // Phase 2: wave w handles ear w&1 of every second query of the workgroup.  The plan is
 // wave-uniform and lives in SGPRs; per output tap a lane computes 4 wrapped offsets (one per set),
 // 16 loads off scalar bases and 16 FMAs with scalar weights.
+// ---------------------------------------------------------------------------
+// a3 + elevation bracket on the device (SURVEY.md section 8f-4): (elev, azim) -> (idx, w)
+// ---------------------------------------------------------------------------
+// Float64 branch of sphere.azim_to_interpolation_params (sphere.py:78-121) and of interpolate_2d's
+// bracket (apply_hrtf.py:199-215, :261-266), same arithmetic as the host's
+// sphere.interpolation_params_batch: node angles are the float32 table values, comparisons run in
+// binary64, the interval width is a float32 subtraction, weights are binary64 divisions.
+// `rings` (host-computed, so both sides use identical constants):
+//   ring_elev[10] f64 = deg2rad(-45..90), ring_start[10], ring_count[10] int32, node_az[187] f32.
+struct RingTable {
+    double ring_elev[10];
+    int ring_start[10];
+    int ring_count[10];
+};
+
+// PYF: the reference's branch for a PYTHON-FLOAT azimuth under NumPy >= 2 (sphere.py:98-105, :119): a Python float is a
+// "weak" scalar, so `index_azim[:,1] <= azim` and `(azim - before_azim) / (after_azim - before_azim)` are evaluated in the
+// table's float32 - the azimuth is rounded to binary32 first (after the binary64 modulo of :86), compared in binary32,
+// and the weight is a binary32 quotient of binary32 differences.  That is what the reference's own trajectory presets
+// (circle_horizontal, circle_askew, spiral: apply_hrtf.py:585-586, :593) feed it.
+template <bool PYF>
+__device__ __forceinline__ void ring_lookup(const RingTable &R, const float *__restrict__ node_az, int ring,
+                                             double az, int &before, int &after, double &a) {
+    if (ring == 9) {                                         // pole: sphere.py:92-93
+        before = after = 186;
+        a = 0.0;
+        return;
+    }
+    const int start = R.ring_start[ring], count = R.ring_count[ring];
+    const float az32 = (float)az;                            // round to nearest even, as numpy converts the weak scalar
+    int j = 0;                                               // last node <= az (node 0 is azimuth 0)
+    for (int i = 1; i < count; ++i)
+        if (PYF ? node_az[start + i] <= az32 : (double)node_az[start + i] <= az) j = i;
+    const bool wrap = j + 1 >= count;
+    const float b32 = node_az[start + j];
+    const float a32 = wrap ? (float)(2.0 * 3.14159265358979323846) : node_az[start + j + 1];
+    const float den = __fsub_rn(a32, b32);                   // float32 subtraction, as sphere.py:119 evaluates it
+    before = start + j;
+    after = wrap ? start : start + j + 1;
+    if (PYF) a = (double)__fdiv_rn(__fsub_rn(az32, b32), den);
+    else a = (az - (double)b32) / (double)den;
+}
+
+// one (elev, azim) -> (top_before, top_after, bot_before, bot_after), (top_alpha, bot_alpha, a)
+template <bool PYF>
+__device__ __forceinline__ void traj_params_one(const RingTable &R, const float *__restrict__ node_az, double e, double az,
+                                                 int (&ix)[4], double (&wt)[3]) {
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    double z = fmod(az, two_pi);                             // numpy's % : result in [0, 2 pi)
+    if (z != 0.0 && z < 0.0) z += two_pi;
+    int hi = 0, lo = 9;                                      // first elevation >= e, last elevation <= e
+    while (hi < 9 && R.ring_elev[hi] < e) ++hi;
+    while (lo > 0 && R.ring_elev[lo] > e) --lo;
+    ring_lookup<PYF>(R, node_az, hi, z, ix[0], ix[1], wt[0]);
+    ring_lookup<PYF>(R, node_az, lo, z, ix[2], ix[3], wt[1]);
+    const double span = R.ring_elev[hi] - R.ring_elev[lo];
+    wt[2] = span > 0.0 ? (e - R.ring_elev[lo]) / span : 0.0;
+}
+
 #define BAS_QB 16      // queries per workgroup
 
+// Where the plan kernel takes a query's parameters from: the (idx, w) arrays, or straight from the trajectory angles
+// (ANG = 1: float64 branch of a3, 2: the Python-float branch) - for SMALL batches, where a separate a3 launch is pure
+// launch latency (one source x 10 s = 863 queries: 5 us per launch); for large ones both ears' threads redoing the
+// angle arithmetic cost more than the launch (221 k queries: 53 us merged against 9 + 15 us).
+struct PlanAngles {
+    const double *elev, *azim;
+    const float *node_az;
+    RingTable R;
+};
+
 // plan kernel: one thread per (query, ear)
+template <int ANG>
 __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__restrict__ diffs,
                                                                   const int32_t *__restrict__ idx,
                                                                   const double *__restrict__ w, int n,
                                                                   int ndir, int L, int U,
-                                                                  EarPlanS *__restrict__ plans) {
+                                                                  EarPlanS *__restrict__ plans, PlanAngles PA) {
     long t = blockIdx.x * 256L + threadIdx.x;
     if (t >= 2L * n) t = 2L * n - 1;                         // (idle threads of the last block redo its last record: barrier below)
     const long q = t >> 1;
     const int e = (int)(t & 1);
     const int M = L * U;
-    const int pt = clamp_dir(idx[4 * q + 0], ndir), qt = clamp_dir(idx[4 * q + 1], ndir);
-    const int pb = clamp_dir(idx[4 * q + 2], ndir), qb = clamp_dir(idx[4 * q + 3], ndir);
-    const double at = w[3 * q + 0], ab = w[3 * q + 1], a = w[3 * q + 2];
+    int ix[4];
+    double wt[3];
+    if constexpr (ANG == 0) {
+        ix[0] = idx[4 * q + 0]; ix[1] = idx[4 * q + 1]; ix[2] = idx[4 * q + 2]; ix[3] = idx[4 * q + 3];
+        wt[0] = w[3 * q + 0]; wt[1] = w[3 * q + 1]; wt[2] = w[3 * q + 2];
+    } else {
+        traj_params_one<ANG == 2>(PA.R, PA.node_az, PA.elev[q], PA.azim[q], ix, wt);
+    }
+    const int pt = clamp_dir(ix[0], ndir), qt = clamp_dir(ix[1], ndir);
+    const int pb = clamp_dir(ix[2], ndir), qb = clamp_dir(ix[3], ndir);
+    const double at = wt[0], ab = wt[1], a = wt[2];
     const double *d = diffs + (long)e * ndir * ndir;
     // delays of the two ring interpolations in non-upsampled samples (apply_hrtf.py:106)
     const double dt = (at * ((double)U * d[(long)pt * ndir + qt])) / (double)U;
@@ -396,9 +474,44 @@ extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, co
                 BAS_E_WORKSPACE, "bas_interp2d_plan_f32: 16-byte aligned buffer of %zu bytes needed, %zu given",
                 bas_interp2d_workspace_bytes(n), plans_bytes);
     const long rows = 2L * n;
-    hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                       bas_stream(stream), diffs, idx, w, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans));
+    hipLaunchKernelGGL(bas_interp2d_plan_kernel<0>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                       bas_stream(stream), diffs, idx, w, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PlanAngles{});
     return bas_check_launch("bas_interp2d_plan_f32");
+}
+
+extern "C" int bas_interp2d_plan_angles_f32(const double *diffs, const double *elev, const double *azim, int n,
+                                            const double *ring_elev, const int32_t *ring_start,
+                                            const int32_t *ring_count, const float *node_az, int branch, int ndir,
+                                            int L, int U, void *plans, size_t plans_bytes, bas_stream_t stream) {
+    BAS_REQUIRE(diffs && ring_elev && ring_start && ring_count && node_az && ((elev && azim) || n == 0), BAS_E_NULL,
+                "bas_interp2d_plan_angles_f32: null pointer");
+    BAS_REQUIRE(n >= 0 && ndir > 0 && L > 0 && U >= BAS_PLAN_MIN_U, BAS_E_SHAPE,
+                "bas_interp2d_plan_angles_f32: need n>=0, ndir>0, L>0, U>=%d (n=%d ndir=%d L=%d U=%d)", BAS_PLAN_MIN_U, n,
+                ndir, L, U);
+    BAS_REQUIRE(branch == BAS_BRANCH_F64 || branch == BAS_BRANCH_PYFLOAT, BAS_E_SHAPE,
+                "bas_interp2d_plan_angles_f32: branch must be BAS_BRANCH_F64 (0) or BAS_BRANCH_PYFLOAT (1), got %d", branch);
+    BAS_REQUIRE((long)2 * ndir * BAS_PLANE(L) * U < (1L << 31), BAS_E_SHAPE, "bas_interp2d_plan_angles_f32: table too large");
+    if (n == 0) return 0;
+    BAS_REQUIRE(plans && plans_bytes >= bas_interp2d_workspace_bytes(n) && reinterpret_cast<uintptr_t>(plans) % 16 == 0,
+                BAS_E_WORKSPACE, "bas_interp2d_plan_angles_f32: 16-byte aligned buffer of %zu bytes needed, %zu given",
+                bas_interp2d_workspace_bytes(n), plans_bytes);
+    PlanAngles PA;
+    PA.elev = elev; PA.azim = azim; PA.node_az = node_az;
+    for (int i = 0; i < 10; ++i) {
+        PA.R.ring_elev[i] = ring_elev[i];
+        PA.R.ring_start[i] = ring_start[i];
+        PA.R.ring_count[i] = ring_count[i];
+        BAS_REQUIRE(PA.R.ring_count[i] > 0 && PA.R.ring_start[i] >= 0 && PA.R.ring_start[i] + PA.R.ring_count[i] <= ndir,
+                    BAS_E_SHAPE, "bas_interp2d_plan_angles_f32: ring %d out of the %d-direction table", i, ndir);
+    }
+    const long rows = 2L * n;
+    if (branch == BAS_BRANCH_PYFLOAT)
+        hipLaunchKernelGGL(bas_interp2d_plan_kernel<2>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                           bas_stream(stream), diffs, nullptr, nullptr, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PA);
+    else
+        hipLaunchKernelGGL(bas_interp2d_plan_kernel<1>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                           bas_stream(stream), diffs, nullptr, nullptr, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PA);
+    return bas_check_launch("bas_interp2d_plan_angles_f32");
 }
 
 extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *idx,
@@ -422,8 +535,8 @@ extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const 
                            w, (long)n, ndir, L, U, H);
         return bas_check_launch("bas_interp2d_f32(generic)");
     }
-    hipLaunchKernelGGL(bas_interp2d_plan_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
-                       w, n, ndir, L, U, plans);
+    hipLaunchKernelGGL(bas_interp2d_plan_kernel<0>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
+                       w, n, ndir, L, U, plans, PlanAngles{});
     int rc = bas_check_launch("bas_interp2d_f32(plan)");
     if (rc) return rc;
     long blocks = ((long)n + 3) / 4;
@@ -480,71 +593,18 @@ extern "C" int bas_ring_interp_f32(const float *packed, const double *diffs, con
     return bas_check_launch("bas_ring_interp_f32");
 }
 
-// ---------------------------------------------------------------------------
-// a3 + elevation bracket on the device (SURVEY.md section 8f-4): (elev, azim) -> (idx, w)
-// ---------------------------------------------------------------------------
-// Float64 branch of sphere.azim_to_interpolation_params (sphere.py:78-121) and of interpolate_2d's
-// bracket (apply_hrtf.py:199-215, :261-266), same arithmetic as the host's
-// sphere.interpolation_params_batch: node angles are the float32 table values, comparisons run in
-// binary64, the interval width is a float32 subtraction, weights are binary64 divisions.
-// `rings` (host-computed, so both sides use identical constants):
-//   ring_elev[10] f64 = deg2rad(-45..90), ring_start[10], ring_count[10] int32, node_az[187] f32.
-struct RingTable {
-    double ring_elev[10];
-    int ring_start[10];
-    int ring_count[10];
-};
-
-// PYF: the reference's branch for a PYTHON-FLOAT azimuth under NumPy >= 2 (sphere.py:98-105, :119): a Python float is a
-// "weak" scalar, so `index_azim[:,1] <= azim` and `(azim - before_azim) / (after_azim - before_azim)` are evaluated in the
-// table's float32 - the azimuth is rounded to binary32 first (after the binary64 modulo of :86), compared in binary32,
-// and the weight is a binary32 quotient of binary32 differences.  That is what the reference's own trajectory presets
-// (circle_horizontal, circle_askew, spiral: apply_hrtf.py:585-586, :593) feed it.
-template <bool PYF>
-__device__ __forceinline__ void ring_lookup(const RingTable &R, const float *__restrict__ node_az, int ring,
-                                             double az, int &before, int &after, double &a) {
-    if (ring == 9) {                                         // pole: sphere.py:92-93
-        before = after = 186;
-        a = 0.0;
-        return;
-    }
-    const int start = R.ring_start[ring], count = R.ring_count[ring];
-    const float az32 = (float)az;                            // round to nearest even, as numpy converts the weak scalar
-    int j = 0;                                               // last node <= az (node 0 is azimuth 0)
-    for (int i = 1; i < count; ++i)
-        if (PYF ? node_az[start + i] <= az32 : (double)node_az[start + i] <= az) j = i;
-    const bool wrap = j + 1 >= count;
-    const float b32 = node_az[start + j];
-    const float a32 = wrap ? (float)(2.0 * 3.14159265358979323846) : node_az[start + j + 1];
-    const float den = __fsub_rn(a32, b32);                   // float32 subtraction, as sphere.py:119 evaluates it
-    before = start + j;
-    after = wrap ? start : start + j + 1;
-    if (PYF) a = (double)__fdiv_rn(__fsub_rn(az32, b32), den);
-    else a = (az - (double)b32) / (double)den;
-}
-
 template <bool PYF>
 __global__ __launch_bounds__(256) void bas_traj_params_kernel(const double *__restrict__ elev,
                                                                 const double *__restrict__ azim, long n,
                                                                 RingTable R, const float *__restrict__ node_az,
                                                                 int32_t *__restrict__ idx,
                                                                 double *__restrict__ w) {
-    const double two_pi = 2.0 * 3.14159265358979323846;
     for (long q = blockIdx.x * 256L + threadIdx.x; q < n; q += (long)gridDim.x * 256L) {
-        const double e = elev[q];
-        double z = fmod(azim[q], two_pi);                    // numpy's % : result in [0, 2 pi)
-        if (z != 0.0 && z < 0.0) z += two_pi;
-        int hi = 0, lo = 9;                                  // first elevation >= e, last elevation <= e
-        while (hi < 9 && R.ring_elev[hi] < e) ++hi;
-        while (lo > 0 && R.ring_elev[lo] > e) --lo;
-        int tb, taf, bb, baf;
-        double ta, ba;
-        ring_lookup<PYF>(R, node_az, hi, z, tb, taf, ta);
-        ring_lookup<PYF>(R, node_az, lo, z, bb, baf, ba);
-        const double span = R.ring_elev[hi] - R.ring_elev[lo];
-        const double a = span > 0.0 ? (e - R.ring_elev[lo]) / span : 0.0;
-        idx[4 * q + 0] = tb; idx[4 * q + 1] = taf; idx[4 * q + 2] = bb; idx[4 * q + 3] = baf;
-        w[3 * q + 0] = ta; w[3 * q + 1] = ba; w[3 * q + 2] = a;
+        int ix[4];
+        double wt[3];
+        traj_params_one<PYF>(R, node_az, elev[q], azim[q], ix, wt);
+        idx[4 * q + 0] = ix[0]; idx[4 * q + 1] = ix[1]; idx[4 * q + 2] = ix[2]; idx[4 * q + 3] = ix[3];
+        w[3 * q + 0] = wt[0]; w[3 * q + 1] = wt[1]; w[3 * q + 2] = wt[2];
     }
 }
 

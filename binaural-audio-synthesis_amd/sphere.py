@@ -251,6 +251,15 @@ def _ring_args():
     return _RING_ARGS[3:]
 
 
+def device_nodes(dev):
+    """The table's 187 node azimuths (float32, sphere.py:318) on `dev`, uploaded once per device."""
+    import torch
+    nodes = _DEVICE_NODES.get(dev.index)
+    if nodes is None:
+        nodes = _DEVICE_NODES[dev.index] = torch.from_numpy(index_elev_azim[:, 2].copy()).to(dev)
+    return nodes
+
+
 def interpolation_params_device(elev, azim, out=None, branch="f64"):
     """interpolation_params_batch on the GPU (bas_traj_params_branch_f64): elev/azim are float64 device
     tensors of equal shape; returns device tensors idx int32 [..., 4], w float64 [..., 3] (written into
@@ -262,9 +271,7 @@ def interpolation_params_device(elev, azim, out=None, branch="f64"):
     from . import _hip
     assert elev.is_cuda and elev.dtype == torch.float64 and azim.shape == elev.shape and azim.dtype == torch.float64
     dev = elev.device
-    nodes = _DEVICE_NODES.get(dev.index)
-    if nodes is None:
-        nodes = _DEVICE_NODES[dev.index] = torch.from_numpy(index_elev_azim[:, 2].copy()).to(dev)
+    nodes = device_nodes(dev)
     e = elev.contiguous().reshape(-1)
     z = azim.contiguous().reshape(-1)
     n = e.numel()

@@ -187,6 +187,15 @@ int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, i
 int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double *w, int n,
                           int ndir, int L, int U, void *plans, size_t plans_bytes,
                           bas_stream_t stream);
+/* bas_traj_params_branch_f64 + bas_interp2d_plan_f32 in ONE launch (a3 and the plan step of a6: sphere.py:78-121,
+ * apply_hrtf.py:199-279), for small batches where a launch costs more than the arithmetic (one source x 10 s is 863
+ * queries; a real-time block of 256 sources is 768): both ears' threads of a query redo the angle arithmetic.
+ * Same plans, bit for bit, as the two calls.  elev / azim [n] f64 device; ring_* host, node_az device, branch as in
+ * bas_traj_params_branch_f64. */
+int bas_interp2d_plan_angles_f32(const double *diffs, const double *elev, const double *azim, int n,
+                                 const double *ring_elev, const int32_t *ring_start,
+                                 const int32_t *ring_count, const float *node_az, int branch, int ndir,
+                                 int L, int U, void *plans, size_t plans_bytes, bas_stream_t stream);
 int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L);
 size_t bas_render_fused_workspace_bytes(int n_src, long T_in, int K, int S, int L);
 int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed,

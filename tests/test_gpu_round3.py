@@ -284,3 +284,32 @@ def test_bench_stream_line_has_a_roofline():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["kernel_ms"] > 0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert d["ps_per_source_sample"] > 0 and d["value"] > 0
+
+
+# ---------------------------------------------------------------------------
+# a3 inside the plan kernel (small batches)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("branch", ["f64", "pyfloat"])
+def test_merged_a3_plan_launch_equals_the_two_launches(tables, branch, monkeypatch):
+    """bas_interp2d_plan_angles_f32 (angles -> read plans in one launch, what small scenes and real-time blocks run)
+    gives the same render, bit for bit, as bas_traj_params_branch_f64 + bas_interp2d_plan_f32; also through the
+    stored-IR path (K = 64: not served by the fused kernel)."""
+    import torch
+    from binaural_audio_synthesis_amd import apply_hrtf
+    h = tables["adversarial"].truncated(128)
+    d = _device_table(h)
+    for k, s in ((512, 32), (64, 32)):
+        n_src, n = 3, 8 * 2048
+        sigs, elev, azim = _scene(n_src, n, k, seed=90)
+        x = torch.from_numpy(sigs).cuda()
+        e, a = torch.from_numpy(elev).cuda(), torch.from_numpy(azim).cuda()
+        monkeypatch.setattr(apply_hrtf, "MERGED_A3_MAX_QUERIES", 1 << 16)
+        merged, pk1 = apply_hrtf.render_angles_device(x, k, s, d, e, a, normalize="none", branch=branch)
+        monkeypatch.setattr(apply_hrtf, "MERGED_A3_MAX_QUERIES", 0)
+        split, pk2 = apply_hrtf.render_angles_device(x, k, s, d, e, a, normalize="none", branch=branch)
+        assert torch.equal(merged, split) and torch.equal(pk1, pk2)
+        idx, w = bas.sphere.interpolation_params_batch(elev, azim, branch=branch)
+        irs = [np.stack([orc.interp2d_from_params(h, idx[i, c, 0], idx[i, c, 1], w[i, c, 0], idx[i, c, 2], idx[i, c, 3],
+                                                  w[i, c, 1], w[i, c, 2]) for c in range(elev.shape[1])]) for i in range(n_src)]
+        want = orc.render_mix(sigs, k, s, irs, normalize=False)
+        assert rel_err(merged.t().cpu().numpy(), want) <= REL
