@@ -65,6 +65,18 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #ifndef FZ_FFA
 #define FZ_FFA 1                // row step as a 2-parallel fast FIR (bas_fir.h: 3/4 of the FMAs); 0: direct form
 #endif
+#ifndef FZ_ASM
+#define FZ_ASM 0                // 1 (make asmstep): the row step of the (h0, d) kernels as ONE hand-scheduled assembly block with
+#endif                          // explicit VGPR numbers (tools/gen_fir_asm.py -> bas_fir_asm.inc: tap reads of half octet u + 1 under
+                                // the FMAs of half u, packed ops 8-byte aligned).  Bit-identical; measured EQUAL to hipcc's
+                                // schedule of bas_fir.h (0.6402 vs 0.6404 ms, profiles/r03_ab_asm_row_step.txt): not the default.
+#if FZ_ASM
+#include "bas_fir_asm.inc"
+#else
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+template <int XR>
+__device__ __forceinline__ void ffa_row_step_asm(f32x32 &, f32x32 &, f32x2 &, f32x32 &, unsigned, unsigned, float, unsigned) {}
+#endif
 #define FZ_HO_MAXEV 9           // h-only rows: chunk IRs per wave (K = 256: 35 rows under a tile of 8192)
 #define FZ_MAXSLOTS 20          // chunk slots under one tile (LDS: two 4-wave workgroups per CU at K >= 448)
 
@@ -150,10 +162,29 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     if (!A.direct && peak_bits && blockIdx.x == 0 && tid == 0) *peak_bits = 0u;   // the reduce kernel maxes into it later
     if (n_pass <= 0) return;
 
+    constexpr bool USE_ASM = FZ_ASM && FZ_FFA && !HONLY;
+    static_assert(!USE_ASM || XR == 261 || XR == 69, "bas_fir_asm.inc holds the row step for these x-image strides");
 #if FZ_FFA
-    f32x2 fa[16], fb[17], fp[16];                            // half-rate partial sums (bas_fir.h), combined in flush()
-    ffa_zero(fa, fb, fp);
-#define FZ_ACC_CLEAR() ffa_zero(fa, fb, fp)
+    // half-rate partial sums (bas_fir.h), combined in flush().  Assembly row step: the same 49 pairs as three 32-float
+    // vectors + one pair, pinned to v[0:97] by the asm statement's register constraints (A = fa, B = fb[0..15], P = fp)
+    f32x2 fa[16], fb[17], fp[16];
+    f32x32 accA, accB, accP;
+    f32x2 accB16 = f32x2{0.f, 0.f};
+    if constexpr (USE_ASM) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) accA[i] = accB[i] = accP[i] = 0.f;
+    } else {
+        ffa_zero(fa, fb, fp);
+    }
+#define FZ_ACC_CLEAR()                                                               \
+    do {                                                                             \
+        if constexpr (USE_ASM) {                                                     \
+            _Pragma("unroll") for (int i = 0; i < 32; ++i) accA[i] = accB[i] = accP[i] = 0.f; \
+            accB16 = f32x2{0.f, 0.f};                                                \
+        } else {                                                                     \
+            ffa_zero(fa, fb, fp);                                                    \
+        }                                                                            \
+    } while (0)
 #else
     f32x2 acc[32];
 #define FZ_ACC_CLEAR()                                        \
@@ -171,7 +202,18 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     auto flush = [&](long tile) {
 #if FZ_FFA
         f32x2 acc[32];
-        ffa_combine(acc, fa, fb, fp);
+        if constexpr (USE_ASM) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {                   // y[2p] = A[p] + B[p-1];  y[2p+1] = P[p] - A[p] - B[p]
+                const f32x2 a = f32x2{accA[2 * p], accA[2 * p + 1]}, b0 = f32x2{accB[2 * p], accB[2 * p + 1]};
+                const f32x2 b1 = p < 15 ? f32x2{accB[2 * p + 2], accB[2 * p + 3]} : accB16;
+                const f32x2 pp = f32x2{accP[2 * p], accP[2 * p + 1]};
+                acc[2 * p] = a + b0;
+                acc[2 * p + 1] = (pp - a) - b1;
+            }
+        } else {
+            ffa_combine(acc, fa, fb, fp);
+        }
 #endif
         if (A.direct) {                                      // uniform
             const long n0 = tile * TILE + 2048 * wv + 32 * lane;        // this lane's first output
@@ -470,10 +512,19 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                 const int t0 = 32 * rp - 32 + 8 * i;
                 if (t0 >= 0 && t0 < Lseg) mk |= 1u << i;
             }
+#if !FZ_FFA
             float xr[32];
             fz_load_xrow<XR>(xr, xrow);
+#endif
 #if FZ_FFA
-            ffa_row_step_x<HONLY>(fa, fb, fp, xr, hd + sl * SLOTF + (32 * rp - 32) * (HONLY ? 2 : 4), al[0], mk);
+            if constexpr (USE_ASM) {
+                ffa_row_step_asm<XR>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow),
+                                     (unsigned)reinterpret_cast<uintptr_t>(hd + sl * SLOTF + (32 * rp - 32) * 4), al[0], mk);
+            } else {
+                float xr[32];
+                fz_load_xrow<XR>(xr, xrow);
+                ffa_row_step_x<HONLY>(fa, fb, fp, xr, hd + sl * SLOTF + (32 * rp - 32) * (HONLY ? 2 : 4), al[0], mk);
+            }
 #else
             hd_row_step_x<1, HONLY>(acc, xr, hd + sl * SLOTF + (32 * rp - 32) * (HONLY ? 2 : 4), al, mk);
 #endif

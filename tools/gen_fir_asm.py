@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Generator of binaural-audio-synthesis_amd/csrc/bas_fir_asm.inc: the row step of the fused FIR kernel
+(bas_fir.h: ffa_row_step_x, the 2-parallel fast FIR on a 32 x 32 Toeplitz block of packed FMAs) as ONE hand-scheduled
+gfx950 assembly block with explicit VGPR numbers.
+
+Why assembly: a wave that has its SIMD to itself - its CU partner is staging - waits
+for the 8 tap reads of every octet before the octet's 98 FMAs (~25 % of its cycles), and hipcc cannot be made to issue
+the reads of octet I + 1 under the FMAs of octet I without spilling hundreds of registers.  Here the taps are double
+buffered in fixed registers, and every 64-bit instruction starts at an address = 0 mod 8 (an instruction at = 4 mod 8
+costs one more issue cycle: profiles/r03_ubench_bank_placement.txt).
+
+Register map (per lane; the accumulators are C++ variables pinned to these registers by "+{v[a:b]}" constraints):
+    v[0:31]    A[p] = g_e * x_e       16 pairs (left, right)         v[98:129]   x row: 32 inputs
+    v[32:63]   B[p-1] = g_o * x_o     entries 0..15                  v[130:145]  x_e + x_o: 16 sums
+    v[64:95]   P[p] = (g_e+g_o)*(x_e+x_o)                            v[146:161]  taps: 4 x (h0_L, h0_R, d_L, d_R)
+    v[96:97]   B entry 16                                            v[162:165] g_e[2]  v[166:169] g_o[2]  v[170:173] g_e + g_o
+                                                                     v[174:175]  crossfade weight (low half)
+Inputs: LDS byte address of the lane's x row, of its tap row (tap - 32 of the row distance), the weight, and the mask of
+live octets (SGPR).  Arithmetic, order of accumulation per accumulator and results are those of ffa_octet_fma.
+
+    python3 tools/gen_fir_asm.py [XR ...]    (XR = column stride of the x image in float4 units = rows + 1; default: 261 69,
+                                              the tiles of 8192 and 2048 outputs)
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "binaural-audio-synthesis_amd", "csrc", "bas_fir_asm.inc")
+
+A0, B0, P0, B16 = 0, 32, 64, 96
+X0, XS0 = 98, 130
+TAP = 146                       # ONE buffer of 4 taps (16 registers): it is dead once the taps are formed
+GE0, GO0, GS0 = 162, 166, 170
+AL = 174
+LAST = 175
+
+
+def pr(r):
+    return f"v[{r}:{r + 1}]"
+
+
+def quad(r):
+    return f"v[{r}:{r + 3}]"
+
+
+def gen(xr_stride):
+    """The schedule works in HALF octets (4 taps = 16 registers): forming the crossfaded taps consumes the tap buffer, so
+    the reads of half u + 1 go out into the SAME buffer right behind the forming of half u and land under its ~49 FMAs.
+    (A whole-octet double buffer needs 60 more registers per lane; those came back as scratch traffic in the staging code
+    around the block: 16 % slower than hipcc's schedule.  Two half-octet buffers: 4 % slower.)"""
+    L = []
+    emit = L.append
+
+    def align():
+        emit(".p2align 3")
+
+    def load_taps(u):
+        i, h = u >> 1, u & 1
+        for j in range(4):
+            emit(f"ds_read_b128 {quad(TAP + 4 * j)}, %[tap] offset:{(8 * i + 4 * h + j) * 16}")
+
+    def form(u):
+        # crossfaded taps of the half octet: g = h0 + al d; even full-rate taps -> g_e, odd -> g_o, and their sums
+        for k in range(2):
+            te, to = TAP + 4 * (2 * k), TAP + 4 * (2 * k + 1)
+            emit(f"v_pk_fma_f32 {pr(GE0 + 2 * k)}, {pr(te + 2)}, {pr(AL)}, {pr(te)} op_sel_hi:[1,0,1]")
+            emit(f"v_pk_fma_f32 {pr(GO0 + 2 * k)}, {pr(to + 2)}, {pr(AL)}, {pr(to)} op_sel_hi:[1,0,1]")
+        for k in range(2):
+            emit(f"v_pk_add_f32 {pr(GS0 + 2 * k)}, {pr(GE0 + 2 * k)}, {pr(GO0 + 2 * k)}")
+
+    def fmas(u):
+        i, h = u >> 1, u & 1
+        for k in range(2):
+            jj = 2 * h + k
+            dk = 4 * i + jj - 16
+            for p in range(-1, 16):
+                q = p - dk
+                if not (0 <= q < 16):
+                    continue
+                xp = pr(X0 + 2 * q)                                  # (x_e[q], x_o[q]) = inputs 2q, 2q + 1
+                xsp, xs_hi = pr(XS0 + 2 * (q >> 1)), q & 1
+                if p >= 0:
+                    emit(f"v_pk_fma_f32 {pr(A0 + 2 * p)}, {pr(GE0 + 2 * k)}, {xp}, {pr(A0 + 2 * p)} op_sel_hi:[1,0,1]")
+                    sel = "op_sel:[0,1,0]" if xs_hi else "op_sel_hi:[1,0,1]"
+                    emit(f"v_pk_fma_f32 {pr(P0 + 2 * p)}, {pr(GS0 + 2 * k)}, {xsp}, {pr(P0 + 2 * p)} {sel}")
+                breg = B16 if p + 1 == 16 else B0 + 2 * (p + 1)
+                emit(f"v_pk_fma_f32 {pr(breg)}, {pr(GO0 + 2 * k)}, {xp}, {pr(breg)} op_sel:[0,1,0]")
+
+    # ---- prologue: weight into its pair, the x row, taps of the first half octet (if live)
+    align()
+    emit(f"v_mov_b32_e64 v{AL}, %[al]")
+    for c in range(8):
+        emit(f"ds_read_b128 {quad(X0 + 4 * c)}, %[xrow] offset:{c * xr_stride * 16}")
+    emit("s_bitcmp1_b32 %[mask], 0")
+    emit("s_cbranch_scc0 L_x_only_%=")
+    load_taps(0)
+    emit("L_x_only_%=:")
+    emit("s_waitcnt lgkmcnt(0)")
+    align()
+    for q in range(16):
+        emit(f"v_add_f32_e64 v{XS0 + q}, v{X0 + 2 * q}, v{X0 + 2 * q + 1}")
+    # ---- octets (both halves of an octet are live or dead together)
+    for i in range(8):
+        emit(f"s_bitcmp1_b32 %[mask], {i}")
+        emit(f"s_cbranch_scc0 L_dead{i}_%=")
+        emit("s_waitcnt lgkmcnt(0)")                        # (its reads went out under the previous half's FMAs)
+        align()
+        form(2 * i)
+        load_taps(2 * i + 1)
+        fmas(2 * i)
+        emit("s_waitcnt lgkmcnt(0)")
+        align()
+        form(2 * i + 1)
+        if i < 7:
+            emit(f"s_bitcmp1_b32 %[mask], {i + 1}")
+            emit(f"s_cbranch_scc0 L_last{i}_%=")
+            load_taps(2 * i + 2)
+            emit(f"L_last{i}_%=:")
+            align()
+        fmas(2 * i + 1)
+        if i < 7:
+            emit(f"s_branch L_end{i}_%=")
+            emit(f"L_dead{i}_%=:")
+            emit(f"s_bitcmp1_b32 %[mask], {i + 1}")
+            emit(f"s_cbranch_scc0 L_end{i}_%=")
+            load_taps(2 * i + 2)
+            emit(f"L_end{i}_%=:")
+        else:
+            emit(f"L_dead{i}_%=:")
+    return L
+
+
+def main():
+    xrs = [int(a) for a in sys.argv[1:]] or [261, 69]          # tiles of 8192 (4 waves) and 2048 (1 wave): 260 / 68 rows + 1
+    clob = ", ".join(f'"v{r}"' for r in range(X0, LAST + 1))
+    text = None
+    for xr in xrs:
+        lines = gen(xr)
+        body = "\n".join(f'        "{ln}\\n\\t"' for ln in lines)
+        n_fma = sum(1 for ln in lines if ln.startswith("v_pk_fma"))
+        if text is None:
+            text = HEAD.format(n_fma=n_fma, xrs=" ".join(str(x) for x in xrs))
+        text += FUNC.format(xr=xr, body=body, clob=clob)
+    with open(OUT, "w") as f:
+        f.write(text)
+    print(f"{OUT}: {len(lines)} lines per variant, {n_fma} packed FMAs")
+
+
+HEAD = """// GENERATED by tools/gen_fir_asm.py {xrs} - do not edit (see that file for the register map and the schedule).
+// Row step of the fused FIR kernel as one gfx950 assembly block: {n_fma} v_pk_fma_f32 (784 FIR + 64 forming), 32 v_pk_add_f32,
+// 16 v_add_f32, 72 ds_read_b128; reads of half octet u + 1 issued right behind the forming of half u, under its FMAs; every
+// 64-bit instruction 8-byte aligned.  Same arithmetic and accumulation order as ffa_row_step_x (bas_fir.h).
+// One instantiation per column stride XR of the x image (float4 units).
+#pragma once
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+
+template <int XR>
+__device__ __forceinline__ void ffa_row_step_asm(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow,
+                                                  unsigned tap, float al, unsigned mask);
+"""
+
+FUNC = """
+template <>
+__device__ __forceinline__ void ffa_row_step_asm<{xr}>(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow,
+                                                  unsigned tap, float al, unsigned mask) {{
+    asm volatile(
+{body}
+        : "+{{v[0:31]}}"(accA), "+{{v[32:63]}}"(accB), "+{{v[64:95]}}"(accP), "+{{v[96:97]}}"(accB16)
+        : [xrow] "v"(xrow), [tap] "v"(tap), [al] "v"(al), [mask] "s"(mask)
+        : "memory", "scc", {clob});
+}}
+"""
+
+
+if __name__ == "__main__":
+    main()
