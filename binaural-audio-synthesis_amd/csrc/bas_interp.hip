@@ -599,12 +599,24 @@ __global__ __launch_bounds__(256) void bas_traj_params_kernel(const double *__re
                                                                 RingTable R, const float *__restrict__ node_az,
                                                                 int32_t *__restrict__ idx,
                                                                 double *__restrict__ w) {
+    // (the body of traj_params_one, written out: through the helper's array references hipcc copies the by-value ring
+    // table into scratch - 168 bytes per lane, 19 us instead of 9 for 221 k boundaries)
+    const double two_pi = 2.0 * 3.14159265358979323846;
     for (long q = blockIdx.x * 256L + threadIdx.x; q < n; q += (long)gridDim.x * 256L) {
-        int ix[4];
-        double wt[3];
-        traj_params_one<PYF>(R, node_az, elev[q], azim[q], ix, wt);
-        idx[4 * q + 0] = ix[0]; idx[4 * q + 1] = ix[1]; idx[4 * q + 2] = ix[2]; idx[4 * q + 3] = ix[3];
-        w[3 * q + 0] = wt[0]; w[3 * q + 1] = wt[1]; w[3 * q + 2] = wt[2];
+        const double e = elev[q];
+        double z = fmod(azim[q], two_pi);                    // numpy's % : result in [0, 2 pi)
+        if (z != 0.0 && z < 0.0) z += two_pi;
+        int hi = 0, lo = 9;                                  // first elevation >= e, last elevation <= e
+        while (hi < 9 && R.ring_elev[hi] < e) ++hi;
+        while (lo > 0 && R.ring_elev[lo] > e) --lo;
+        int tb, taf, bb, baf;
+        double ta, ba;
+        ring_lookup<PYF>(R, node_az, hi, z, tb, taf, ta);
+        ring_lookup<PYF>(R, node_az, lo, z, bb, baf, ba);
+        const double span = R.ring_elev[hi] - R.ring_elev[lo];
+        const double a = span > 0.0 ? (e - R.ring_elev[lo]) / span : 0.0;
+        idx[4 * q + 0] = tb; idx[4 * q + 1] = taf; idx[4 * q + 2] = bb; idx[4 * q + 3] = baf;
+        w[3 * q + 0] = ta; w[3 * q + 1] = ba; w[3 * q + 2] = a;
     }
 }
 
