@@ -62,8 +62,10 @@ def main(argv=None):
         # fixed directions exactly as written at :610-611 (note `% 2*np.pi` binds as (x % 2) * pi)
         left = lambda t: (0, ((2 * np.pi / (8 * fs) + np.pi / 2) % 2 * np.pi))            # noqa: E731
         right = lambda t: (0, ((2 * np.pi / (8 * fs) + 3 * np.pi / 2) % 2 * np.pi))       # noqa: E731
-        left_out = apply_hrtf.make_signal_move_2d(y[:, 0], args.chunksize, args.subchunksize, left, tbl).astype(np.float32)
-        right_out = apply_hrtf.make_signal_move_2d(y[:, 1], args.chunksize, args.subchunksize, right, tbl).astype(np.float32)
+        left_out = apply_hrtf.make_signal_move_2d(y[:, 0], args.chunksize, args.subchunksize, left, tbl,
+                                                  vectorized=True).astype(np.float32)
+        right_out = apply_hrtf.make_signal_move_2d(y[:, 1], args.chunksize, args.subchunksize, right, tbl,
+                                                   vectorized=True).astype(np.float32)
         out_sig = 0.5 * (left_out + right_out)                              # :616
         out_filename = '{}-binaural-stereo.wav'.format(args.input.replace('.wav', ''))    # :617
         wavfile.write(out_filename, fs, out_sig.astype(np.float32))
@@ -73,7 +75,11 @@ def main(argv=None):
         return out_filename
     if len(y.shape) == 2 and y.shape[1] == 2:
         y = 0.5 * y[:, 0] + 0.5 * y[:, 1]                                   # :630
-    out_sig = apply_hrtf.make_signal_move_2d(y, args.chunksize, args.subchunksize, traj, tbl).astype(np.float32)
+    # vectorized=True: the preset is evaluated once for all chunk times and turned into interpolation parameters on the
+    # GPU, in whichever of the reference's two numeric branches the preset selects (Python-float azimuths - circle_horizontal,
+    # circle_askew, spiral - take the float32 branch, np.float64 ones the float64 branch: apply_hrtf.trajectory_branch)
+    out_sig = apply_hrtf.make_signal_move_2d(y, args.chunksize, args.subchunksize, traj, tbl,
+                                             vectorized=True).astype(np.float32)
     out_filename = '{}-c{}-s{}-l{}.wav'.format(args.input.replace('.wav', ''), args.chunksize,
                                                args.subchunksize, args.samples_to_keep)               # :636-639
     wavfile.write(out_filename, fs, out_sig.astype(np.float32))             # :640

@@ -313,3 +313,55 @@ def test_merged_a3_plan_launch_equals_the_two_launches(tables, branch, monkeypat
                                                   w[i, c, 1], w[i, c, 2]) for c in range(elev.shape[1])]) for i in range(n_src)]
         want = orc.render_mix(sigs, k, s, irs, normalize=False)
         assert rel_err(merged.t().cpu().numpy(), want) <= REL
+
+
+def test_stream_graph_replay_beside_a_busy_producer_thread(tables):
+    """input_view()'s docstring recommends a producer thread.  After prepare() no process() call captures,
+    so a second thread that allocates device memory and copies on its own stream all the time (what invalidates a
+    capture in 'global' mode) cannot disturb the stream: 60 blocks through graph replays == the whole-signal render."""
+    import threading
+    import torch
+    h = tables["consistent"].truncated(128)
+    d = _device_table(h)
+    n_src, k, s, B, nblocks = 4, 512, 32, 1024, 60
+    sigs, elev, azim = _scene(n_src, B * nblocks, k, seed=120)
+    whole = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none")
+    st = bas.StreamRenderer(d, n_src, k, s)
+    st.input_view(B)
+    st.prepare(B)
+    g0 = st._graph
+    stop = threading.Event()
+    count = [0]
+
+    def producer():
+        side = torch.cuda.Stream()
+        host = torch.empty((256, 1024), dtype=torch.float32).pin_memory()
+        while not stop.is_set():
+            with torch.cuda.stream(side):
+                t = torch.empty((256, 1024), dtype=torch.float32, device="cuda")   # hipMalloc / allocator traffic
+                t.copy_(host, non_blocking=True)
+                t.mul_(2.0)
+            side.synchronize()
+            count[0] += 1
+
+    th = threading.Thread(target=producer, daemon=True)
+    th.start()
+    import time
+    t_wait = time.time()
+    while count[0] < 3 and time.time() - t_wait < 60:       # the producer is up and cycling before the stream starts
+        time.sleep(0.001)
+    try:
+        outs = []
+        sig_dev = torch.from_numpy(sigs).cuda()
+        e_dev, a_dev = torch.from_numpy(elev).cuda(), torch.from_numpy(azim).cuda()
+        for b in range(nblocks):
+            c0 = b * B // k
+            outs.append(st.process(sig_dev[:, b * B:(b + 1) * B], e_dev[:, c0:c0 + B // k + 1], a_dev[:, c0:c0 + B // k + 1]))
+            assert st._graph is g0
+        outs.append(st.finish())
+    finally:
+        stop.set()
+        th.join(timeout=30)
+    got = torch.cat(outs, dim=0)
+    assert count[0] >= 3
+    assert rel_err(got.cpu().numpy(), whole.cpu().numpy()) <= 1e-6
