@@ -77,6 +77,9 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 template <int XR>
 __device__ __forceinline__ void ffa_row_step_asm(f32x32 &, f32x32 &, f32x2 &, f32x32 &, unsigned, unsigned, float, unsigned) {}
 #endif
+#ifndef FZ_PREFETCH
+#define FZ_PREFETCH 1           // the x window and the read plans of pass i + 1 are requested in front of the FIR phase of pass i and
+#endif                          // travel under it (44 registers per lane held across the row steps); 0: requested at the pass's top
 #define FZ_HO_MAXEV 9           // h-only rows: chunk IRs per wave (K = 256: 35 rows under a tile of 8192)
 #define FZ_MAXSLOTS 20          // chunk slots under one tile (LDS: two 4-wave workgroups per CU at K >= 448)
 
@@ -150,16 +153,16 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     float *hd = reinterpret_cast<float *>(lds4) + XFLOATS;   // [nslots][HD_SLOT]: (h0_L, h0_R, d_L, d_R) per tap
                                                              // (HONLY: [nslots + 1][HO_SLOT]: (h_L, h_R) per tap)
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid0 = threadIdx.x;
+    const int lane0 = tid0 & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
 
     const long unit0 = (long)blockIdx.x * A.units_per_wg;
     long unit1 = unit0 + A.units_per_wg;
     if (unit1 > A.units_total) unit1 = A.units_total;
     const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
     const long n_pass = (unit1 - unit0) * nseg;
-    if (!A.direct && peak_bits && blockIdx.x == 0 && tid == 0) *peak_bits = 0u;   // the reduce kernel maxes into it later
+    if (!A.direct && peak_bits && blockIdx.x == 0 && tid0 == 0) *peak_bits = 0u;   // the reduce kernel maxes into it later
     if (n_pass <= 0) return;
 
     constexpr bool USE_ASM = FZ_ASM && FZ_FFA && !HONLY;
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         }
 #endif
         if (A.direct) {                                      // uniform
-            const long n0 = tile * TILE + 2048 * wv + 32 * lane;        // this lane's first output
+            const long n0 = tile * TILE + 2048 * wv + 32 * lane0;       // this lane's first output
             float lmax = 0.f;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             FZ_ACC_CLEAR();
             return;
         }
-        float *dst = slab_wg + (tile - first_tile) * 2 * TILE + 2048 * wv + 32 * lane;
+        float *dst = slab_wg + (tile - first_tile) * 2 * TILE + 2048 * wv + 32 * lane0;
         f32x4 *l4 = reinterpret_cast<f32x4 *>(dst);
         f32x4 *r4 = reinterpret_cast<f32x4 *>(dst + TILE);
 #pragma unroll
@@ -270,11 +273,26 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     long tile = first_tile;
     int s = (int)(unit0 - first_tile * A.n_src);
     int sg = 0;
-    // window geometry, recomputed only when (tile, segment) changes
-    long geo_tile = -1;
-    int geo_sg = -1;
-    int seg0 = 0, Lseg = 0, halo = 0, nrows = 0, c0 = 0, mo0 = 0;
-    long xbase = 0;
+    // window geometry of a (tile, segment); recomputed only when either changes
+    struct Geo {
+        int seg0, Lseg, halo, nrows, c0, mo0;
+        long xbase;
+    };
+    auto make_geo = [&](long t, int g) {
+        Geo G;
+        G.seg0 = g * RT_SEG;
+        G.Lseg = A.Lp - G.seg0 < RT_SEG ? A.Lp - G.seg0 : RT_SEG;
+        G.halo = (G.Lseg + 31) >> 5;                         // input rows above the tile that matter
+        G.xbase = t * TILE - G.seg0 - 32L * G.halo;          // first input sample in LDS (multiple of 32)
+        G.nrows = TILE / 32 + G.halo;
+        long cf = G.xbase / A.K;                             // floor division, consistent across 0
+        if (cf * A.K > G.xbase) --cf;
+        G.c0 = (int)cf;
+        G.mo0 = (int)(G.xbase - cf * A.K);
+        return G;
+    };
+    Geo G = make_geo(tile, sg);
+    long open_tile = -1;                                     // tile whose partial sums the accumulators hold
     // this wave's share of the chunk IRs.  HONLY: rows [slot_a, slot_b) of the nslots + 1 (h_L, h_R) rows, one chunk IR
     // each.  (h0, d) slots: the nslots + 1 chunk IRs are dealt in balanced contiguous ranges [slot_a, slot_b) - 5, 5, 4, 4
     // for the 18 IRs under a tile of 8192 at K = 512 - and a wave writes the slots [slot_a, slot_b): slot i holds
@@ -316,51 +334,32 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     if constexpr (!HONLY && NW > 1) {                        // hand-over flags of the boundary IRs: no pass has id 0
         f32x4 *pl_base0 = reinterpret_cast<f32x4 *>(hd + ((nrows_h * SLOTF + 3) & ~3));
         unsigned *flags0 = reinterpret_cast<unsigned *>(pl_base0 + NW * (MAXEV * PL4) + NW * 64);
-        if (tid < NW) flags0[tid] = 0u;                      // (ordered before their first use by the first pass's barrier)
+        if (tid0 < NW) flags0[tid0] = 0u;                      // (ordered before their first use by the first pass's barrier)
     }
-    for (long pid = 0; pid < n_pass; ++pid) {
-        FZ_STAMP_NW(t0);
-        if (tile != geo_tile || sg != geo_sg) {
-            if (tile != geo_tile && geo_tile >= 0) flush(geo_tile);
-            geo_tile = tile;
-            geo_sg = sg;
-            seg0 = sg * RT_SEG;
-            Lseg = A.Lp - seg0 < RT_SEG ? A.Lp - seg0 : RT_SEG;
-            halo = (Lseg + 31) >> 5;                         // input rows above the tile that matter
-            xbase = tile * TILE - seg0 - 32L * halo;         // first input sample in LDS (multiple of 32)
-            nrows = TILE / 32 + halo;
-            long cf = xbase / A.K;                           // floor division, consistent across 0
-            if (cf * A.K > xbase) --cf;
-            c0 = (int)cf;
-            mo0 = (int)(xbase - cf * A.K);
-        }
-
-#if FZ_STAGE_PRIO
-        __builtin_amdgcn_s_setprio(FZ_STAGE_PRIO);           // staging is latency bound: its few instructions go first
-#endif
-        // ---- global -> registers: this wave's read plans (chunk IRs slot_a .. slot_b, both ears) and the x window
-        f32x4 pv[NPV];
-        {
-            const f32x4 *pl_src = reinterpret_cast<const f32x4 *>(plans) + (long)s * (A.n_chunks + 1) * PL4;
+    // ---- global -> registers: this wave's read plans (chunk IRs slot_a .. slot_b, both ears) and the x window of a pass
+    auto plan_src = [&](int lane, int r, const Geo &Gq, int src) {
+        const f32x4 *pl_src = reinterpret_cast<const f32x4 *>(plans) + (long)src * (A.n_chunks + 1) * PL4;
+        int p = lane + 64 * r;                               // 16-byte piece of the wave's n_ev * 18
+        p = p < n_ev * PL4 ? p : 0;
+        const int i = (p * 3641) >> 16;                      // p / 18 for p < 1000
+        const int c = clampi(Gq.c0 + slot_a + i, 0, A.n_chunks);
+        return pl_src + (long)c * PL4 + (p - i * PL4);
+    };
+    auto issue_plans = [&](int lane, const Geo &Gq, int src, f32x4 (&pv)[NPV]) {
 #pragma unroll
-            for (int r = 0; r < NPV; ++r) {
-                int p = lane + 64 * r;                       // 16-byte piece of the wave's n_ev * 18
-                p = p < n_ev * PL4 ? p : 0;
-                const int i = (p * 3641) >> 16;              // p / 18 for p < 1000
-                const int c = clampi(c0 + slot_a + i, 0, A.n_chunks);
+        for (int r = 0; r < NPV; ++r) {
 #if FZ_NT_LOADS
-                pv[r] = __builtin_nontemporal_load(pl_src + (long)c * PL4 + (p - i * PL4));
+            pv[r] = __builtin_nontemporal_load(plan_src(lane, r, Gq, src));
 #else
-                pv[r] = pl_src[(long)c * PL4 + (p - i * PL4)];
+            pv[r] = *plan_src(lane, r, Gq, src);
 #endif
-            }
         }
-        const float *xwin = x + (long)s * A.x_stride + xbase;
-        const long lo_l = -xbase, hi_l = A.T_in - xbase;     // offsets of the signal's first sample / one past its last
+    };
+    auto issue_x = [&](int tid, const Geo &Gq, int src, f32x4 (&xv)[NX]) {
+        const float *xwin = x + (long)src * A.x_stride + Gq.xbase;
+        const long lo_l = -Gq.xbase, hi_l = A.T_in - Gq.xbase;
         const int x_lo = lo_l < -(1 << 30) ? -(1 << 30) : (lo_l > (1 << 30) ? (1 << 30) : (int)lo_l);
         const int x_hi = hi_l < -(1 << 30) ? -(1 << 30) : (hi_l > (1 << 30) ? (1 << 30) : (int)hi_l);
-        const bool x_inside = x_lo <= 0 && x_hi >= 4 * NX * THREADS;   // whole window inside the signal
-        f32x4 xv[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             int i = 4 * (tid + j * THREADS);
@@ -372,6 +371,40 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             xv[j] = *reinterpret_cast<const f32x4 *>(xwin + i);
 #endif
         }
+    };
+    // prefetch: the NEXT pass's x window is requested in front of the FIR phase and held in 36 registers per lane across the
+    // row steps - only the assembly row step (78 operand registers against ~104 of hipcc's schedule) leaves them: with
+    // hipcc's row step the same source spills 166 registers; its read plans go by LDS-DMA straight into the wave's plan
+    // region, which is dead during the FIR phase (no registers at all)
+    constexpr bool PREFETCH = FZ_PREFETCH && USE_ASM && NW == 4;
+    f32x4 pv[NPV], xv[NX];
+    for (long pid = 0; pid < n_pass; ++pid) {
+        // the thread index is made opaque once per pass: everything derived from it (load / LDS addresses, tap indices, masks) is
+        // then recomputed per pass - a few dozen integer ops - instead of being hoisted out of the loop and held in (or spilled
+        // from) registers across the FIR phase, whose row step needs them all
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63;
+        FZ_STAMP_NW(t0);
+        if (tile != open_tile) {                             // the accumulators belong to another tile: hand them over
+            if (open_tile >= 0) flush(open_tile);
+            open_tile = tile;
+        }
+        const int seg0 = G.seg0, Lseg = G.Lseg, halo = G.halo, nrows = G.nrows, mo0 = G.mo0;
+        const long xbase = G.xbase;
+
+#if FZ_STAGE_PRIO
+        __builtin_amdgcn_s_setprio(FZ_STAGE_PRIO);           // staging is latency bound: its few instructions go first
+#endif
+        const bool fetched = PREFETCH && pid > 0;           // (requested in front of the previous FIR phase)
+        if (!fetched) {
+            issue_plans(lane, G, s, pv);
+            issue_x(tid, G, s, xv);
+        }
+        const long lo_l = -xbase, hi_l = A.T_in - xbase;     // offsets of the signal's first sample / one past its last
+        const int x_lo = lo_l < -(1 << 30) ? -(1 << 30) : (lo_l > (1 << 30) ? (1 << 30) : (int)lo_l);
+        const int x_hi = hi_l < -(1 << 30) ? -(1 << 30) : (hi_l > (1 << 30) ? (1 << 30) : (int)hi_l);
+        const bool x_inside = x_lo <= 0 && x_hi >= 4 * NX * THREADS;   // whole window inside the signal
         FZ_STAMP_NW(t1);
         __syncthreads();                                     // previous pass has finished reading LDS
         FZ_STAMP_NW(t2);
@@ -383,9 +416,13 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         f32x4 *bnd = pl_base + NW * (MAXEV * PL4);                       // [NW][64]: a wave's first chunk IR, lane-linear
         volatile unsigned *flags = reinterpret_cast<volatile unsigned *>(bnd + NW * 64);   // [NW]: pass id of bnd[w]
         const unsigned pass_id = (unsigned)pid + 1u;
+        if (!fetched) {
 #pragma unroll
-        for (int r = 0; r < NPV; ++r)
-            if (lane + 64 * r < n_ev * PL4) plw[lane + 64 * r] = pv[r];
+            for (int r = 0; r < NPV; ++r)
+                if (lane + 64 * r < n_ev * PL4) plw[lane + 64 * r] = pv[r];
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the plans' LDS-DMA has landed (only this wave reads them)
+        }
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             const int i4 = tid + j * THREADS;
@@ -475,6 +512,32 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         __syncthreads();
         FZ_STAMP_NW(t5);
 
+        // ---- next (tile, source, segment); its x window and read plans are requested now and arrive under the FIR phase
+        long n_tile = tile;
+        int n_s = s, n_sg = sg + 1;
+        if (n_sg == nseg) {
+            n_sg = 0;
+            if (++n_s == A.n_src) {
+                n_s = 0;
+                ++n_tile;
+            }
+        }
+        Geo GN = G;
+        if (n_tile != tile || n_sg != sg) GN = make_geo(n_tile, n_sg);
+        if constexpr (PREFETCH) {
+            if (pid + 1 < n_pass) {
+#if defined(__HIP_DEVICE_COMPILE__)                          // (the builtin exists in the device pass only)
+                typedef __attribute__((address_space(3))) void *lds_ptr_t;
+#pragma unroll
+                for (int r = 0; r < NPV; ++r)
+                    if (lane + 64 * r < n_ev * PL4)          // (inactive lanes write nothing: the region holds n_ev * 18 pieces)
+                        __builtin_amdgcn_global_load_lds(plan_src(lane, r, GN, n_s),
+                                                         (lds_ptr_t)(uintptr_t)(unsigned)reinterpret_cast<uintptr_t>(plw + 64 * r), 16, 0, 2);
+#endif
+                issue_x(tid, GN, n_s, xv);
+            }
+        }
+
         // ---- FIR: input rows rho' = 0..halo above/at the lane's output row
         const int row_out = 64 * wv + lane + halo;           // window row holding the lane's outputs
         const int pos = mo0 + 32 * row_out;
@@ -538,18 +601,14 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
 
         FZ_STAMP_NW(t6);
         FZ_ADD(0, t0, t1); FZ_ADD(1, t1, t2); FZ_ADD(2, t2, t3); FZ_ADD(3, t3, t4); FZ_ADD(4, t4, t5); FZ_ADD(5, t5, t6);
-        // ---- next (tile, source, segment)
-        if (++sg == nseg) {
-            sg = 0;
-            if (++s == A.n_src) {
-                s = 0;
-                ++tile;
-            }
-        }
+        tile = n_tile;
+        s = n_s;
+        sg = n_sg;
+        G = GN;
     }
-    flush(geo_tile);
+    flush(open_tile);
 #ifdef BAS_STAMPS
-    if (lane == 0 && blockIdx.x < 2048) {
+    if (lane0 == 0 && blockIdx.x < 2048) {
         unsigned long long *d = bas_fz_stamps + (blockIdx.x * 4 + wv) * 8;
         for (int i = 0; i < 6; ++i) d[i] = st_acc[i];
 #ifdef BAS_LIFETIME_ONLY
