@@ -1,10 +1,10 @@
 cd /root/repo
 python - <<'PY'
 import os, sys, subprocess
-# run the GPU parity tests with the assembly build as the library under test
+# (historic helper: the assembly row step is the shipped build now; kept for A/B builds: set LIB below)
 import binaural_audio_synthesis_amd as bas
 from binaural_audio_synthesis_amd import _hip
-_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libbas_hip_asmstep.so")
+_hip.LIB_PATH = os.path.join(os.path.dirname(_hip.LIB_PATH), "libbas_hip.so")
 import pytest
 sys.exit(pytest.main(["tests/test_gpu_parity.py", "tests/test_gpu_round2.py", "tests/test_gpu_round3.py", "-q", "-x", "-m", "gpu",
                       "-k", "not bench and not cabi and not nccl and not two_ranks and not hook and not diag"]))
