@@ -52,7 +52,7 @@ echo "[7] shares done"
 #    round's evaluation scheme (21 IRs per pass), packed runs aligned to 8 bytes
 ( cd $C && for lib in libbas_noeval.so libbas_prev.so; do [ -f $lib ] || echo "missing $lib"; done
   python3 ../../tools/ab_fir.py --rounds 7 --reps 20 --no-check libbas_hip.so libbas_noeval.so > $O/ab_noeval.txt 2>&1
-  python3 ../../tools/ab_fir.py --rounds 7 --reps 20 libbas_prev.so libbas_hip.so > $O/ab_ir_sharing.txt 2>&1 )
+  python3 ../../tools/ab_fir.py --rounds 7 --reps 20 libbas_prev.so libbas_hip_cppstep.so libbas_hip.so > $O/ab_ir_sharing.txt 2>&1 )
 # 9. phase stamps of the fused kernel (diagnostic build)
 python3 tools/stamps_fz.py 256 2>/dev/null > $O/stamps_fz_256.txt
 # 10. two ranks on one device (rehearsal of the multi-rank bench path under gloo)
