@@ -131,7 +131,8 @@ def gen(xr_stride):
 
 
 def main():
-    xrs = [int(a) for a in sys.argv[1:]] or [261, 69]          # tiles of 8192 (4 waves) and 2048 (1 wave): 260 / 68 rows + 1
+    check = "--check" in sys.argv[1:]                           # compare with the committed file instead of writing it
+    xrs = [int(a) for a in sys.argv[1:] if a != "--check"] or [261, 69]   # tiles of 8192 (4 waves) and 2048 (1 wave): 260 / 68 rows + 1
     clob = ", ".join(f'"v{r}"' for r in range(X0, LAST + 1))
     text = None
     for xr in xrs:
@@ -141,6 +142,10 @@ def main():
         if text is None:
             text = HEAD.format(n_fma=n_fma, xrs=" ".join(str(x) for x in xrs))
         text += FUNC.format(xr=xr, body=body, clob=clob)
+    if check:
+        same = os.path.exists(OUT) and open(OUT).read() == text
+        print(f"{OUT}: {'up to date' if same else 'DIFFERS from what the generator writes'}")
+        sys.exit(0 if same else 1)
     with open(OUT, "w") as f:
         f.write(text)
     print(f"{OUT}: {len(lines)} lines per variant, {n_fma} packed FMAs")
