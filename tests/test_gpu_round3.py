@@ -365,3 +365,18 @@ def test_stream_graph_replay_beside_a_busy_producer_thread(tables):
     got = torch.cat(outs, dim=0)
     assert count[0] >= 3
     assert rel_err(got.cpu().numpy(), whole.cpu().numpy()) <= 1e-6
+
+
+def test_bench_stream_mode_through_the_collective_path():
+    """`bench.py --mode stream --force-pg`: ShardedStreamRenderer with a real RCCL communicator of size 1 - one gather of the
+    [2, B] partial block per block - prints the same kind of line, with the collective path named."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--mode", "stream", "--sources", "12", "--fs", "48000",
+                        "--block", "8192", "--steps", "5", "--warmup", "1", "--force-pg"], capture_output=True, text=True,
+                       timeout=600, env=_clean_env(), cwd=_root())
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # RCCL's banner must not reach stdout
+    d = json.loads(lines[0])
+    assert d["collective_path"] == "nccl world_size=1" and d["value"] > 0 and d["peak"] > 0
