@@ -27,6 +27,7 @@
 #include "bas_internal.h"
 #include "bas_plan.h"
 #include "bas_fir.h"
+#include "bas_fused.h"
 #include <stdlib.h>
 
 #ifdef BAS_STAMPS
@@ -65,58 +66,14 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #ifndef FZ_FFA
 #define FZ_FFA 1                // row step as a 2-parallel fast FIR (bas_fir.h: 3/4 of the FMAs); 0: direct form
 #endif
-#ifndef FZ_ASM
-#define FZ_ASM 1                // the row step of the (h0, d) kernels as ONE hand-scheduled assembly block with explicit VGPR numbers
-#endif                          // (tools/gen_fir_asm.py -> bas_fir_asm.inc, generated by the Makefile: tap reads of half octet u + 1 under
-                                // the FMAs of half u, packed ops 8-byte aligned).  Bit-identical to hipcc's schedule of bas_fir.h (0) and
-                                // by itself no faster - but it holds 78 operand registers where hipcc's holds ~104, which is what lets the
-                                // next pass's x window travel under the FIR phase (FZ_PREFETCH): together -1.0 .. -1.5 % kernel time
-                                // (profiles/r03_ab_asm_row_step.txt)
-#if FZ_ASM
-#include "bas_fir_asm.inc"
-#else
-typedef float f32x32 __attribute__((ext_vector_type(32)));
-template <int XR>
-__device__ __forceinline__ void ffa_row_step_asm(f32x32 &, f32x32 &, f32x2 &, f32x32 &, unsigned, unsigned, float, unsigned) {}
+#ifndef FZ_SPLIT
+#define FZ_SPLIT FZ_ASM            // scenes with at least three (tile, source) units per CU: the split-role kernel (bas_fused_split.hip)
 #endif
 #ifndef FZ_PREFETCH
 #define FZ_PREFETCH 1           // the x window and the read plans of pass i + 1 are requested in front of the FIR phase of pass i and
 #endif                          // travel under it (44 registers per lane held across the row steps); 0: requested at the pass's top
 #define FZ_HO_MAXEV 9           // h-only rows: chunk IRs per wave (K = 256: 35 rows under a tile of 8192)
 #define FZ_MAXSLOTS 20          // chunk slots under one tile (LDS: two 4-wave workgroups per CU at K >= 448)
-
-// (the four arrays are separate __restrict__ kernel parameters, not members: only then can the compiler prove
-// that the slab stores never clobber the plans and fetch them through the scalar cache)
-struct FzArgs {
-    long x_stride;
-    int n_src;
-    long T_in;
-    int K, S, L, Lp;            // Lp = L rounded up to a multiple of 8
-    int n_chunks;
-    int s_pow2;                 // S is a power of two
-    float invK, invS;
-    long units_total;           // n_tiles * n_src
-    int units_per_wg, parts_per_wg;
-    int nslots;                 // chunk slots staged per pass (covers every window of this K and tile)
-    int spw;                    // chunk slots per wave = ceil(nslots / NW)
-    unsigned packed_bytes;
-    // direct output: every tile is finished by ONE workgroup (units_per_wg is a multiple of n_src, e.g. a single
-    // source), so the accumulators go straight to y and no slab / reduce pass exists
-    int direct;
-    int accumulate;
-    long T_out;
-};
-
-// Lanes l < 32 hold four taps of the left ear, lanes l + 32 the same taps of the right ear.  After two half-wave
-// swaps lane l holds taps 2, 3 of both ears and lane l + 32 taps 0, 1 of both ears: (t_a L, t_a R), (t_b L, t_b R).
-__device__ __forceinline__ void fz_pair_ears(const f32x4 &h, f32x2 &ta, f32x2 &tb) {
-    // permlane32_swap(vdst, src): lanes 32-63 of vdst <-> lanes 0-31 of src
-    const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h.z), __float_as_uint(h.x), false, false);
-    const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(h.w), __float_as_uint(h.y), false, false);
-    // s0[0] = [L t2 | L t0], s0[1] = [R t2 | R t0] (lower lanes | upper lanes); s1 likewise for t3 / t1
-    ta = f32x2{__uint_as_float(s0[0]), __uint_as_float(s0[1])};
-    tb = f32x2{__uint_as_float(s1[0]), __uint_as_float(s1[1])};
-}
 
 template <int XR>
 __device__ __forceinline__ void fz_load_xrow(float (&xr)[32], const f32x4 *__restrict__ xrow) {
@@ -560,6 +517,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
 #elif FZ_STAGE_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
+#pragma unroll 1
         for (int rp = 0; rp <= halo; ++rp) {
             float al[1];
             if (A.s_pow2) {
@@ -571,12 +529,13 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                 if (r >= A.S) q += 1;
                 al[0] = (float)(q * A.S) * A.invK;
             }
-            unsigned mk = 0;                                 // octet i holds taps 32 rp - 32 + 8 i .. +7 of the segment
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int t0 = 32 * rp - 32 + 8 * i;
-                if (t0 >= 0 && t0 < Lseg) mk |= 1u << i;
-            }
+            // octet i holds taps t0 = 32 rp - 32 + 8 i .. + 7 of the segment and is live for 0 <= t0 < Lseg (a multiple of 8):
+            // i in [lo, hi).  (Closed form: eight compare-and-or chains per row step were 60 scalar instructions, which a wave
+            // that has its SIMD to itself pays ~6 clocks each for.)
+            const int oct_lo = 4 - 4 * rp > 0 ? 4 - 4 * rp : 0;
+            int oct_hi = (Lseg + 32 - 32 * rp) >> 3;         // >= 1 for rp <= halo
+            oct_hi = oct_hi > 8 ? 8 : oct_hi;
+            const unsigned mk = ((1u << oct_hi) - 1u) & ~((1u << oct_lo) - 1u);
 #if !FZ_FFA
             float xr[32];
             fz_load_xrow<XR>(xr, xrow);
@@ -633,6 +592,7 @@ extern "C" int bas_debug_read_fz_stamps(unsigned long long *host, size_t count) 
 // ---------------------------------------------------------------------------
 struct FzPlan {
     int nw;                    // waves per workgroup: 4 or 1 (0: shape not served)
+    int split;                 // one workgroup of 4 filter + 4 stager waves per CU (bas_fused_split.hip)
     int honly;                 // LDS rows hold (h_L, h_R) only (chunk sizes below ~448)
     int tile, nslots, spw;
     long n_tiles, units_total;
@@ -748,15 +708,24 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         if (getenv("BAS_FZ_WG_PER_CU")) wg_per_cu = atoi(getenv("BAS_FZ_WG_PER_CU"));   // diagnostic: a workgroup alone on its CU
 #endif
         if (wg_per_cu < 1) continue;
-        const long slots = wg_per_cu * cus;
+        long slots = wg_per_cu * cus;
         const long n_tiles = (T_out + 2048L * nw - 1) / (2048L * nw);
         const long units = n_tiles * n_src;
+        // split roles (one workgroup per CU, the staging of unit u + 1 under the FIR of unit u): worth it from three units per
+        // workgroup on (the first unit's staging is exposed); needs two (x image, taps) buffers in LDS
+        const bool split_fits = FZ_SPLIT && nw == 4 && wg_per_cu == 2 && bas_fs_lds_bytes(nslots) <= 160 * 1024;
+        bool split = split_fits && units >= 3L * cus;
+#ifdef BAS_DIAG
+        if (getenv("BAS_FZ_SPLIT")) split = split_fits && atoi(getenv("BAS_FZ_SPLIT")) != 0;   // (1: also for small scenes)
+#endif
+        if (split) slots = cus;
 #ifdef BAS_DIAG
         if (units < slots && nw > 1 && !force_nw) continue;
 #else
         if (units < slots && nw > 1) continue;               // not enough work for this tile: try a smaller one
 #endif
         p.nw = nw;
+        p.split = split ? 1 : 0;
         p.tile = 2048 * nw;
         p.nslots = nslots;
         p.spw = spw;
@@ -766,7 +735,7 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         p.units_per_wg = (int)((units + wg - 1) / wg);
         p.n_wg = (int)((units + p.units_per_wg - 1) / p.units_per_wg);
         p.parts_per_wg = (p.units_per_wg + n_src - 2) / n_src + 1;
-        p.lds_bytes = lds;
+        p.lds_bytes = split ? bas_fs_lds_bytes(nslots) : lds;
         p.slab_bytes = (size_t)p.n_wg * p.parts_per_wg * 2 * p.tile * sizeof(float);
         return p;
     }
@@ -776,6 +745,15 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
 extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L) {
     return fz_plan(n_src, T_in, K, S, L).nw ? 1 : 0;
 }
+
+#ifdef BAS_DIAG
+// diagnostic build only (tests, tools/stress_fused.py): which kernel a shape gets - waves per workgroup | h-only rows << 4 |
+// split roles << 5 (0: not served)
+extern "C" int bas_debug_fused_plan(int n_src, long T_in, int K, int S, int L) {
+    const FzPlan p = fz_plan(n_src, T_in, K, S, L);
+    return p.nw | (p.honly << 4) | (p.split << 5);
+}
+#endif
 
 extern "C" size_t bas_render_fused_workspace_bytes(int n_src, long T_in, int K, int S, int L) {
     return fz_plan(n_src, T_in, K, S, L).slab_bytes + 16;
@@ -843,11 +821,20 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
     A.accumulate = accumulate;
     A.T_out = T_out;
     float *slab = reinterpret_cast<float *>(ws);
+    hipEvent_t eb = reinterpret_cast<hipEvent_t>(ev_begin), ee = reinterpret_cast<hipEvent_t>(ev_end);
+    if (p.split) {
+        hipError_t e = bas_fs_launch(A, x, slab, packed, reinterpret_cast<const unsigned *>(plans), y, peak_bits, p.n_wg,
+                                     p.lds_bytes, st, eb, ee);
+        if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int rc = bas_check_launch("bas_render_mix_fused_f32(fs)");
+        if (rc || A.direct) return rc;
+        return bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
+                                      peak_bits, st, "bas_render_mix_fused_f32(reduce)");
+    }
     typedef void (*fz_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
     const fz_fn fn = p.honly ? bas_render_fz_kernel<4, true> : p.nw == 4 ? bas_render_fz_kernel<4, false> : bas_render_fz_kernel<1, false>;
     hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
     if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    hipEvent_t eb = reinterpret_cast<hipEvent_t>(ev_begin), ee = reinterpret_cast<hipEvent_t>(ev_end);
     if (eb) (void)hipEventRecord(eb, st);
     hipLaunchKernelGGL(fn, dim3(p.n_wg), dim3(64 * p.nw), p.lds_bytes, st, A, x, slab, packed,
                        reinterpret_cast<const unsigned *>(plans), y, peak_bits);

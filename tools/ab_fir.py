@@ -49,6 +49,7 @@ wsp = torch.empty((_hip.lib().bas_interp2d_workspace_bytes(idx.shape[0]),), dtyp
 handles = [(_hip.use_library(p if os.path.isabs(p) else os.path.join(os.getcwd(), p)), os.path.basename(p)) for p in args.libs]
 res = {name: ([], []) for _, name in handles}
 ref = None
+worst = {}
 for rnd in range(args.rounds + 1):
     for ctx, name in handles:
         with ctx:
@@ -65,8 +66,10 @@ for rnd in range(args.rounds + 1):
             else:
                 scale = float(ref.abs().max())
                 err = float((y - ref).abs().max()) / scale if scale > 0 else float(y.abs().max())
+                worst[name] = max(worst.get(name, 0.0), err)
                 assert args.no_check or err < 1e-5, (name, err)          # (builds may differ in summation order: the tests' tolerance)
             if rnd > 0:
                 res[name][0].append(sum(ms) / len(ms)); res[name][1].append(el)
 for name, (km, st) in res.items():
-    print(f"{name:40s} FIR kernel ms: median {statistics.median(km):.4f} min {min(km):.4f} max {max(km):.4f} | step ms (plans+FIR+reduce) median {statistics.median(st):.4f}")
+    print(f"{name:40s} FIR kernel ms: median {statistics.median(km):.4f} min {min(km):.4f} max {max(km):.4f} | step ms (plans+FIR+reduce) median {statistics.median(st):.4f}"
+          + (f" | max rel. difference from the first build {worst[name]:.1e}" if name in worst else ""))

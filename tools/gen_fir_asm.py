@@ -33,6 +33,7 @@ TAP = 146                       # ONE buffer of 4 taps (16 registers): it is dea
 GE0, GO0, GS0 = 162, 166, 170
 AL = 174
 LAST = 175
+NOWAIT = NOBRANCH = NOTAPS = NOALIGN = NOX = GENERIC_ONLY = False
 
 
 def pr(r):
@@ -49,7 +50,19 @@ def gen(xr_stride):
     (A whole-octet double buffer needs 60 more registers per lane; those came back as scratch traffic in the staging code
     around the block: 16 % slower than hipcc's schedule.  Two half-octet buffers: 4 % slower.)"""
     L = []
-    emit = L.append
+
+    def emit(ln):
+        if NOWAIT and ln.startswith("s_waitcnt"):
+            return
+        if NOBRANCH and (ln.startswith("s_bitcmp") or ln.startswith("s_cbranch") or ln.startswith("s_branch")):
+            return
+        if NOTAPS and ln.startswith("ds_read") and "%[tap]" in ln:
+            return
+        if NOX and ln.startswith("ds_read") and "%[xrow]" in ln:
+            return
+        if NOALIGN and ln.startswith(".p2align"):
+            return
+        L.append(ln)
 
     def align():
         emit(".p2align 3")
@@ -86,20 +99,51 @@ def gen(xr_stride):
                 breg = B16 if p + 1 == 16 else B0 + 2 * (p + 1)
                 emit(f"v_pk_fma_f32 {pr(breg)}, {pr(GO0 + 2 * k)}, {xp}, {pr(breg)} op_sel:[0,1,0]")
 
-    # ---- prologue: weight into its pair, the x row, taps of the first half octet (if live)
-    align()
-    emit(f"v_mov_b32_e64 v{AL}, %[al]")
-    for c in range(8):
-        emit(f"ds_read_b128 {quad(X0 + 4 * c)}, %[xrow] offset:{c * xr_stride * 16}")
-    emit("s_bitcmp1_b32 %[mask], 0")
-    emit("s_cbranch_scc0 L_x_only_%=")
-    load_taps(0)
-    emit("L_x_only_%=:")
-    emit("s_waitcnt lgkmcnt(0)")
-    align()
-    for q in range(16):
-        emit(f"v_add_f32_e64 v{XS0 + q}, v{X0 + 2 * q}, v{X0 + 2 * q + 1}")
-    # ---- octets (both halves of an octet are live or dead together)
+    def prologue(first_live):
+        """weight into its pair, the x row, taps of the first half octet; first_live: None = by the mask (octet 0), else the
+        number of the first live octet (straight-line variants)"""
+        align()
+        emit(f"v_mov_b32_e64 v{AL}, %[al]")
+        for c in range(8):
+            emit(f"ds_read_b128 {quad(X0 + 4 * c)}, %[xrow] offset:{c * xr_stride * 16}")
+        if first_live is None:
+            emit("s_bitcmp1_b32 %[mask], 0")
+            emit("s_cbranch_scc0 L_x_only_%=")
+            load_taps(0)
+            emit("L_x_only_%=:")
+        else:
+            load_taps(2 * first_live)
+        emit("s_waitcnt lgkmcnt(0)")
+        align()
+        for q in range(16):
+            emit(f"v_add_f32_e64 v{XS0 + q}, v{X0 + 2 * q}, v{X0 + 2 * q + 1}")
+
+    def straight(lo, hi, tag):
+        """octets lo .. hi - 1 live, known at assembly time: no mask tests, no branches"""
+        emit(f"L_{tag}_%=:")
+        prologue(lo)
+        for i in range(lo, hi):
+            emit("s_waitcnt lgkmcnt(0)")
+            align()
+            form(2 * i)
+            load_taps(2 * i + 1)
+            fmas(2 * i)
+            emit("s_waitcnt lgkmcnt(0)")
+            align()
+            form(2 * i + 1)
+            if i + 1 < hi:
+                load_taps(2 * i + 2)
+            fmas(2 * i + 1)
+
+    # ---- the masks of a 128-tap segment (0xff: rows 1-3, 0xf0: row 0, 0x0f: row 4) run straight-line code; any other
+    # mask (shorter segments) takes the general block below.  A wave that has its SIMD to itself pays ~6 clocks for every
+    # scalar instruction (profiles/r03_ubench_lone_wave.txt): the mask tests and branches were 9 % of a row step.
+    if not NOBRANCH and not GENERIC_ONLY:
+        for m, tag in ((0xff, "ff"), (0xf0, "f0"), (0x0f, "0f")):
+            emit(f"s_cmp_eq_u32 %[mask], {m}")
+            emit(f"s_cbranch_scc1 L_{tag}_%=")
+    # ---- general block: octets by the mask (both halves of an octet are live or dead together)
+    prologue(None)
     for i in range(8):
         emit(f"s_bitcmp1_b32 %[mask], {i}")
         emit(f"s_cbranch_scc0 L_dead{i}_%=")
@@ -118,6 +162,8 @@ def gen(xr_stride):
             emit(f"L_last{i}_%=:")
             align()
         fmas(2 * i + 1)
+        if NOBRANCH:
+            continue
         if i < 7:
             emit(f"s_branch L_end{i}_%=")
             emit(f"L_dead{i}_%=:")
@@ -127,12 +173,151 @@ def gen(xr_stride):
             emit(f"L_end{i}_%=:")
         else:
             emit(f"L_dead{i}_%=:")
+    if not NOBRANCH and not GENERIC_ONLY:
+        emit("s_branch L_done_%=")
+        straight(0, 8, "ff")
+        emit("s_branch L_done_%=")
+        straight(4, 8, "f0")
+        emit("s_branch L_done_%=")
+        straight(0, 4, "0f")
+        emit("L_done_%=:")
     return L
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The whole (tile, source) unit of a 128-tap segment as ONE block (split-role kernel, bas_fused_split.hip: the filter waves
+# have no staging state to keep, so the block may hold 126 operand registers).  Five row steps rp = 0..4 with the octets
+# 4-7 | 0-7 | 0-7 | 0-7 | 0-3 live = 32 octets in a row, and what the per-step block cannot do:
+#   * the x row of step r + 1 is read into the OTHER x buffer under the last octet of step r, its first taps likewise: no
+#     exposed LDS latency at a step's start (5 x ~200 clocks per unit for a wave that has its SIMD to itself);
+#   * taps are read one whole octet ahead into two half-octet buffers, so every wait is an lgkmcnt(N > 0) that is met;
+#   * no mask tests, no branches, no per-step address arithmetic between the steps (tap address and weight of every step are
+#     operands).
+U_XA, U_XB, U_XS = 98, 130, 162
+U_T = (178, 194)
+U_GE, U_GO, U_GS = 210, 214, 218
+U_AL = 222
+U_LAST = 223
+U_STEPS = ((4, 8), (0, 8), (0, 8), (0, 8), (0, 4))
+
+
+def gen_unit(xr_stride):
+    L = []
+    emit = L.append
+    queue = []                                                  # tags of the LDS reads in flight, oldest first
+
+    def align():
+        emit(".p2align 3")
+
+    def issue(tag, line):
+        emit(line)
+        queue.append(tag)
+
+    def wait_for(tag):
+        """LDS reads return in order: wait until no read with this tag is in flight"""
+        if tag not in queue:
+            return
+        last = max(k for k, t in enumerate(queue) if t == tag)
+        n = len(queue) - 1 - last
+        assert n <= 15
+        emit(f"s_waitcnt lgkmcnt({n})")
+        del queue[:last + 1]
+        align()
+
+    def load_x(r):
+        xb = U_XA if r % 2 == 0 else U_XB
+        for c in range(8):
+            issue(f"x{r}", f"ds_read_b128 {quad(xb + 4 * c)}, %[xrow] offset:{(4 - r) * 16 + c * xr_stride * 16}")
+
+    def load_taps(r, i, h):
+        for j in range(4):
+            issue(f"t{r}.{i}.{h}", f"ds_read_b128 {quad(U_T[h] + 4 * j)}, %[tap{r}] offset:{(8 * i + 4 * h + j) * 16}")
+
+    def form(h):
+        tb = U_T[h]
+        for k in range(2):
+            te, to = tb + 4 * (2 * k), tb + 4 * (2 * k + 1)
+            emit(f"v_pk_fma_f32 {pr(U_GE + 2 * k)}, {pr(te + 2)}, {pr(U_AL)}, {pr(te)} op_sel_hi:[1,0,1]")
+            emit(f"v_pk_fma_f32 {pr(U_GO + 2 * k)}, {pr(to + 2)}, {pr(U_AL)}, {pr(to)} op_sel_hi:[1,0,1]")
+        for k in range(2):
+            emit(f"v_pk_add_f32 {pr(U_GS + 2 * k)}, {pr(U_GE + 2 * k)}, {pr(U_GO + 2 * k)}")
+
+    def fmas(xb, i, h):
+        for k in range(2):
+            jj = 2 * h + k
+            dk = 4 * i + jj - 16
+            for p in range(-1, 16):
+                q = p - dk
+                if not (0 <= q < 16):
+                    continue
+                xp = pr(xb + 2 * q)
+                xsp, xs_hi = pr(U_XS + 2 * (q >> 1)), q & 1
+                if p >= 0:
+                    emit(f"v_pk_fma_f32 {pr(A0 + 2 * p)}, {pr(U_GE + 2 * k)}, {xp}, {pr(A0 + 2 * p)} op_sel_hi:[1,0,1]")
+                    sel = "op_sel:[0,1,0]" if xs_hi else "op_sel_hi:[1,0,1]"
+                    emit(f"v_pk_fma_f32 {pr(P0 + 2 * p)}, {pr(U_GS + 2 * k)}, {xsp}, {pr(P0 + 2 * p)} {sel}")
+                breg = B16 if p + 1 == 16 else B0 + 2 * (p + 1)
+                emit(f"v_pk_fma_f32 {pr(breg)}, {pr(U_GO + 2 * k)}, {xp}, {pr(breg)} op_sel:[0,1,0]")
+
+    octets = [(r, i) for r, (lo, hi) in enumerate(U_STEPS) for i in range(lo, hi)]
+    emit("s_waitcnt lgkmcnt(0)")                               # (scalar loads of the code around the block return out of order)
+    align()
+    load_x(0)
+    load_taps(*octets[0], 0)
+    load_taps(*octets[0], 1)
+    for n, (r, i) in enumerate(octets):
+        xb = U_XA if r % 2 == 0 else U_XB
+        nxt = octets[n + 1] if n + 1 < len(octets) else None
+        if i == U_STEPS[r][0]:                                  # first octet of a step: its x row, the sums, the weight
+            wait_for(f"x{r}")
+            for q in range(16):
+                emit(f"v_add_f32_e64 v{U_XS + q}, v{xb + 2 * q}, v{xb + 2 * q + 1}")
+            emit(f"v_mov_b32_e64 v{U_AL}, %[al{r}]")
+        last_of_step = i == U_STEPS[r][1] - 1
+        for h in range(2):
+            wait_for(f"t{r}.{i}.{h}")
+            form(h)
+            if h == 0 and last_of_step and r + 1 < len(U_STEPS):
+                load_x(r + 1)                                   # (in front of the next octet's taps: it is needed first)
+            if nxt:
+                load_taps(*nxt, h)
+            fmas(xb, i, h)
+    assert not queue
+    return L
+
+
+UNIT_FUNC = """
+// One (tile, source) unit of a 128-tap segment in one block (see tools/gen_fir_asm.py: gen_unit): {n_fma} v_pk_fma_f32,
+// {n_ds} ds_read_b128, {n_wait} waits.  xrow4 = LDS address of the lane's x row of step 4 (the lowest: step r reads 16 (4 - r)
+// bytes above); tap[r], al[r] = tap row address and crossfade weight of step r.
+template <int XR>
+__device__ __forceinline__ void ffa_unit_asm(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
+                                              const unsigned (&tap)[5], const float (&al)[5]);
+template <>
+__device__ __forceinline__ void ffa_unit_asm<{xr}>(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
+                                              const unsigned (&tap)[5], const float (&al)[5]) {{
+    asm volatile(
+{body}
+        : "+{{v[0:31]}}"(accA), "+{{v[32:63]}}"(accB), "+{{v[64:95]}}"(accP), "+{{v[96:97]}}"(accB16)
+        : [xrow] "v"(xrow4), [tap0] "v"(tap[0]), [tap1] "v"(tap[1]), [tap2] "v"(tap[2]), [tap3] "v"(tap[3]), [tap4] "v"(tap[4]),
+          [al0] "v"(al[0]), [al1] "v"(al[1]), [al2] "v"(al[2]), [al3] "v"(al[3]), [al4] "v"(al[4])
+        : "memory", {clob});
+}}
+"""
 
 
 def main():
     check = "--check" in sys.argv[1:]                           # compare with the committed file instead of writing it
-    xrs = [int(a) for a in sys.argv[1:] if a != "--check"] or [261, 69]   # tiles of 8192 (4 waves) and 2048 (1 wave): 260 / 68 rows + 1
+    # diagnostic variants (wrong results; tools/ubench_lone_wave.hip): --nowait no waits for the LDS reads, --nobranch no octet
+    # masks (all live), --notaps no tap reads, --noalign no alignment padding, --nox no x-row reads; --out=FILE
+    global NOWAIT, NOBRANCH, NOTAPS, NOALIGN, NOX, OUT, GENERIC_ONLY
+    GENERIC_ONLY = "--generic" in sys.argv[1:]                  # (A/B: the round-3 block before the straight-line variants)
+    NOWAIT, NOBRANCH, NOTAPS = ("--" + k in sys.argv[1:] for k in ("nowait", "nobranch", "notaps"))
+    NOALIGN, NOX = ("--" + k in sys.argv[1:] for k in ("noalign", "nox"))
+    for a in sys.argv[1:]:
+        if a.startswith("--out="):
+            OUT = a[6:]
+    xrs = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [261, 69]   # tiles of 8192 (4 waves) and 2048 (1 wave): 260 / 68 rows + 1
     clob = ", ".join(f'"v{r}"' for r in range(X0, LAST + 1))
     text = None
     for xr in xrs:
@@ -142,6 +327,13 @@ def main():
         if text is None:
             text = HEAD.format(n_fma=n_fma, xrs=" ".join(str(x) for x in xrs))
         text += FUNC.format(xr=xr, body=body, clob=clob)
+    if 261 in xrs and not GENERIC_ONLY:
+        ul = gen_unit(261)
+        text += UNIT_FUNC.format(xr=261, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
+                                 clob=", ".join(f'"v{r}"' for r in range(U_XA, U_LAST + 1)),
+                                 n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
+                                 n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),
+                                 n_wait=sum(1 for ln in ul if ln.startswith("s_waitcnt")))
     if check:
         same = os.path.exists(OUT) and open(OUT).read() == text
         print(f"{OUT}: {'up to date' if same else 'DIFFERS from what the generator writes'}")

@@ -1,13 +1,19 @@
 #!/usr/bin/env python3
 """Randomised check of the fused path (bas_render_fz_kernel: tiles of 8192 and 2048, h-only rows for chunk sizes below
 448, direct output, slab reduce, wide reduce, several tap segments) against the oracle on the adversarial table: random IR lengths, chunk / subchunk sizes,
-source counts and signal lengths, random (not smooth) trajectories.   python tools/stress_fused.py [cases] [seed]"""
+source counts and signal lengths, random (not smooth) trajectories.   python tools/stress_fused.py [cases] [seed] [split]
+"split": through the diagnostic build with BAS_FZ_SPLIT=1, which gives every scene with at least one (tile of 8192, source) unit
+per CU the split-role kernel (bas_fused_split.hip; the shipped library asks for three units per CU)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import binaural_audio_synthesis_amd as bas
 from oracle import bas_oracle as orc
 
+force_split = len(sys.argv) > 3 and sys.argv[3] == "split"
+if force_split:
+    os.environ["BAS_FZ_SPLIT"] = "1"
+    bas._hip.set_library(bas._hip.DIAG_LIB_PATH)
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 full = bas.synth.make_table("adversarial", 1)
@@ -16,14 +22,16 @@ worst, seen = 0.0, {}
 t_start = time.time()
 for case in range(cases):
     l = int(rng.choice([1, 7, 64, 100, 128, 128, 128, 129, 200, 300]))
+    if force_split and case % 2 == 0:
+        l = 128 - case % 8                                    # every other case: one whole 128-tap segment (L = 122 .. 128)
     s = 32 * int(rng.integers(1, 9))
-    small_k = rng.random() < 0.3                              # chunk sizes 256 .. 447: the fused kernel's h-only rows
+    small_k = rng.random() < (0.1 if force_split else 0.3)                            # chunk sizes 256 .. 447: the fused kernel's h-only rows
     if small_k:
         s = 32 * int(rng.integers(1, 5))
         k = s * int(rng.integers(-(-256 // s), max(-(-256 // s) + 1, 447 // s + 1)))
     else:
         k = s * int(rng.integers(max(1, -(-448 // s)), max(2, 4096 // s) + 1))
-    big = small_k or rng.random() < 0.35                      # enough (tile, source) units for tiles of 8192
+    big = small_k or rng.random() < (0.7 if force_split else 0.35)                     # enough (tile, source) units for tiles of 8192
     n_src = int(rng.integers(24, 48)) if big else int(rng.integers(1, 9))
     n = int(rng.integers(100000, 160000)) if big else int(rng.integers(1, 40000))
     h = full.truncated(l)
@@ -41,6 +49,11 @@ for case in range(cases):
     worst = max(worst, err)
     units4 = -(-(in_length + l - 1) // 8192) * n_src
     kind = ("h-only" if k < 448 else "tile8192") if units4 >= 512 else "tile2048"
+    if force_split:                                           # (the diagnostic build says which kernel the shape got)
+        import ctypes
+        lib.bas_debug_fused_plan.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        code = lib.bas_debug_fused_plan(n_src, in_length, k, s, l)
+        kind = ("split-unit" if (l + 7) // 8 * 8 == 128 else "split") if code & 32 else ("h-only" if code & 16 else f"tile{2048 * (code & 15)}")
     seen[kind] = seen.get(kind, 0) + 1
     print(f"case {case:3d} L={l:4d} K={k:5d} S={s:4d} n_src={n_src:3d} n={n:6d} {kind} rel err {err:.2e}", flush=True)
     assert got.shape == want.shape and err < 1e-5, "PARITY FAILURE"
