@@ -297,7 +297,8 @@ def stream_mode(args):
                           "roofline": {"bound": "hbm", "bound_actual": "fp32 VALU (see the scene line)",
                                        "achieved": algo_bytes / (fir_ms / 1e3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                        "frac": algo_bytes / (fir_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                                       "kernel": "bas_render_fz_kernel", "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes,
+                                       "kernel": bas._hip.lib().bas_render_fused_kernel_name(n_src, B + loc.halo, k, s, l).decode(),
+                                       "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes,
                                        "note": f"algorithmic bytes of one block on this GPU ({n_src} sources): inputs once, stereo "
                                                f"block once, table, 28 B per chunk boundary; the kernel also re-reads a "
                                                f"{loc.halo}-sample halo per source.  kernel_ms: HIP events around the FIR kernel in "
@@ -380,7 +381,8 @@ class Scene:
         self.peak = torch.empty((1,), dtype=torch.float32, device=dev)
         self.fused = False if args.unfused else None             # ablation: --unfused forces interp2d + render_mix
         self.fused_used = bool(lib.bas_render_fused_supported(n_src, in_length, k, s, l)) and self.fused is not False
-        self.kernel = "bas_render_fz_kernel" if self.fused_used else lib.bas_render_kernel_name(n_src, in_length, k, s, l).decode()
+        self.kernel = (lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() if self.fused_used
+                       else lib.bas_render_kernel_name(n_src, in_length, k, s, l).decode())
         self.host_u = host_u
 
     def render_into(self, y_buf, events):

@@ -41,6 +41,7 @@ SIGNATURES = {
     "bas_interp2d_plan_angles_f32": (_c_int, [_c_void_p, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                               _c_void_p, _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_size_t, _c_void_p]),
     "bas_render_fused_supported": (_c_int, [_c_int, _c_long, _c_int, _c_int, _c_int]),
+    "bas_render_fused_kernel_name": (ctypes.c_char_p, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_fused_workspace_bytes": (_c_size_t, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_mix_fused_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_long, _c_int,
                                           _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
@@ -53,7 +54,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3                                                      # BAS_ABI_VERSION of include/bas.h
+ABI_VERSION = 4                                                      # BAS_ABI_VERSION of include/bas.h
 DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libbas_hip_diag.so")   # -DBAS_DIAG build: reads BAS_FORCE_KERNEL (tests only)
 
 

@@ -746,6 +746,13 @@ extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, in
     return fz_plan(n_src, T_in, K, S, L).nw ? 1 : 0;
 }
 
+extern "C" const char *bas_render_fused_kernel_name(int n_src, long T_in, int K, int S, int L) {
+    const FzPlan p = fz_plan(n_src, T_in, K, S, L);
+    if (!p.nw) return "";
+    if (p.split) return FS_UNIT_BLOCK_DEFAULT && ((L + 7) & ~7) == RT_SEG ? "bas_render_fs_kernel<1>" : "bas_render_fs_kernel<0>";
+    return p.honly ? "bas_render_fz_kernel<4,1>" : p.nw == 4 ? "bas_render_fz_kernel<4,0>" : "bas_render_fz_kernel<1,0>";
+}
+
 #ifdef BAS_DIAG
 // diagnostic build only (tests, tools/stress_fused.py): which kernel a shape gets - waves per workgroup | h-only rows << 4 |
 // split roles << 5 (0: not served)

@@ -18,9 +18,6 @@
 #ifndef FZ_NT_LOADS
 #define FZ_NT_LOADS 1
 #endif
-#ifndef FS_UNIT_BLOCK
-#define FS_UNIT_BLOCK 1         // 128-tap segments: the five row steps of a unit as ONE assembly block (0: five per-step blocks)
-#endif
 
 #ifdef BAS_STAMPS
 // Diagnostic build only (make stamps): per wave, in 10 ns ticks: [0] work of the role (staging or FIR + flush), [1] waiting
@@ -326,17 +323,32 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             const int x_hi = hi_l < -(1 << 30) ? -(1 << 30) : (hi_l > (1 << 30) ? (1 << 30) : (int)hi_l);
             const bool x_inside = x_lo <= 0 && x_hi >= 4 * NX * THREADS;   // whole window inside the signal
             {
+                // (every VALU instruction of a stager takes a slot from the filter wave of its SIMD: a window inside the signal -
+                // all but a tile's first and last - is fetched with ONE per-lane offset and scalar bases, no clamping)
                 const float *xwin = x + (long)s * A.x_stride + xbase;
+                if (x_inside) {
+                    const f32x4 *xq = reinterpret_cast<const f32x4 *>(xwin);
 #pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    int i = 4 * (tid + j * THREADS);
-                    i = i < x_lo ? x_lo : i;
-                    i = i > x_hi - 4 ? x_hi - 4 : i;         // clamped into the row (T_in is a multiple of K >= 32)
+                    for (int j = 0; j < NX; ++j) {
 #if FZ_NT_LOADS
-                    xv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xwin + i));   // streamed once
+                        xv[j] = __builtin_nontemporal_load(xq + j * THREADS + tid);                  // streamed once
 #else
-                    xv[j] = *reinterpret_cast<const f32x4 *>(xwin + i);
+                        xv[j] = xq[j * THREADS + tid];
 #endif
+                    }
+                } else {
+                    asm volatile("" ::: "memory");           // (keeps the two forms apart: merged, every load pays the clamps)
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) {
+                        int i = 4 * (tid + j * THREADS);
+                        i = i < x_lo ? x_lo : i;
+                        i = i > x_hi - 4 ? x_hi - 4 : i;     // clamped into the row (T_in is a multiple of K >= 32)
+#if FZ_NT_LOADS
+                        xv[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(xwin + i));
+#else
+                        xv[j] = *reinterpret_cast<const f32x4 *>(xwin + i);
+#endif
+                    }
                 }
             }
             // ---- registers -> LDS: plans into this wave's own region, the x window as a column-major image
@@ -344,15 +356,21 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
 #pragma unroll
             for (int r = 0; r < NPV; ++r)
                 if (lane + 64 * r < n_ev * PL4) plw[lane + 64 * r] = pv[r];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                const int i4 = tid + j * THREADS;
-                f32x4 v = xv[j];
+            {
+                f32x4 *xcol = xs4 + (tid & 7) * XR + (tid >> 3);            // quad i4 = tid + 256 j: column i4 & 7, row (tid >> 3) + 32 j
                 if (!x_inside) {                             // uniform: only windows that overlap an end of the signal
-                    const int e = 4 * i4;                    // x_lo, x_hi are multiples of 4: all four in or out
-                    if (!(e >= x_lo && e < x_hi)) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < NX; ++j) {
+                        const int e = 4 * (tid + j * THREADS);   // x_lo, x_hi are multiples of 4: all four in or out
+                        if (!(e >= x_lo && e < x_hi)) xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 }
-                if (i4 < nrows * 8) xs4[(i4 & 7) * XR + (i4 >> 3)] = v;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    // (rows: 256 + halo >= 257, i.e. at least 2056 quads: only the last of the nine can lie outside)
+                    if ((j + 1) * THREADS <= (TILE / 32 + 1) * 8 || tid + j * THREADS < nrows * 8) xcol[32 * j] = xv[j];
+                }
             }
             __builtin_amdgcn_wave_barrier();                 // other lanes of this wave read the plan words below
 

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BAS_ABI_VERSION 3
+#define BAS_ABI_VERSION 4
 
 #define BAS_E_NULL      (-1)   /* a required pointer is NULL                    */
 #define BAS_E_SHAPE     (-2)   /* inconsistent or unsupported sizes             */
@@ -173,7 +173,7 @@ int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, i
  * leaves n*2 read plans of 144 bytes in `plans` (bas_interp2d_workspace_bytes(n) bytes,
  * 16-byte aligned; query order [n_src][T_in/K + 1]; needs U >= 4).
  * bas_render_mix_fused_f32 is bas_render_mix_f32 with H replaced by (packed table, plans):
- * every workgroup evaluates the chunk IRs it needs while staging (plans staged in LDS,
+ * the workgroups evaluate the chunk IRs they need while staging (plans staged in LDS,
  * table samples by buffer loads), so the [n][2][L] IR array never exists in HBM.
  * Served for chunk sizes K >= 448 or so (K % 32 == 0) with subchunks that are multiples
  * of 32, and for K >= 256 when the scene has at least two workgroups' worth of
@@ -197,6 +197,12 @@ int bas_interp2d_plan_angles_f32(const double *diffs, const double *elev, const 
                                  const int32_t *ring_count, const float *node_az, int branch, int ndir,
                                  int L, int U, void *plans, size_t plans_bytes, bas_stream_t stream);
 int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L);
+/* Name of the kernel bas_render_mix_fused_f32 launches for these operands, for profiling tools ("" when the sizes are
+ * not served): "bas_render_fs_kernel<1>" / "<0>" - one workgroup of four filter and four stager waves per CU, two LDS
+ * buffers (scenes with at least three (tile of 8192, source) units per CU; <1>: L = 121 .. 128, a unit's five row steps
+ * as one assembly block) - or "bas_render_fz_kernel<4,0>" / "<1,0>" / "<4,1>": two workgroups per CU in which every wave
+ * stages and filters (tiles of 8192 / 2048 outputs; <4,1>: chunk sizes below ~448, h-only LDS rows). */
+const char *bas_render_fused_kernel_name(int n_src, long T_in, int K, int S, int L);
 size_t bas_render_fused_workspace_bytes(int n_src, long T_in, int K, int S, int L);
 int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed,
                              const void *plans, int n_src, long T_in, int K, int S, int L,

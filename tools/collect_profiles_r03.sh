@@ -48,14 +48,19 @@ for n in 32 64 128 256; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_share32 -o bench -- python3 bench.py --sources 32 --steps 200 --warmup 10 --no-cpu-baseline --no-self-check > /dev/null 2>> $O/share.err
 echo "[7] shares done"
-# 8. ablations, one process each, interleaved rounds: no chunk-IR evaluation (floor of the FIR part), the previous
-#    round's evaluation scheme (21 IRs per pass), packed runs aligned to 8 bytes
-( cd $C && for lib in libbas_noeval.so libbas_prev.so; do [ -f $lib ] || echo "missing $lib"; done
-  python3 ../../tools/ab_fir.py --rounds 7 --reps 20 --no-check libbas_hip.so libbas_noeval.so > $O/ab_noeval.txt 2>&1
-  python3 ../../tools/ab_fir.py --rounds 7 --reps 20 libbas_prev.so libbas_hip_cppstep.so libbas_hip.so > $O/ab_ir_sharing.txt 2>&1 )
-# 9. phase stamps of the fused kernel (diagnostic build)
-python3 tools/stamps_fz.py 256 2>/dev/null > $O/stamps_fz_256.txt
+# 8. the two fused kernels in one process, interleaved rounds: two workgroups per CU (every wave stages and filters;
+#    make -C csrc nosplit) against the split-role kernel the shipped library picks for these scenes
+( cd $C && [ -f libbas_hip_nosplit.so ] || echo "missing libbas_hip_nosplit.so (make nosplit)"
+  for n in 256 128 64 32; do
+    echo "== $n sources"; python3 ../../tools/ab_fir.py --sources $n --rounds 5 --reps 10 libbas_hip_nosplit.so libbas_hip.so 2>&1 | tail -2
+  done > $O/ab_split_roles.txt 2>&1 )
+# 9. where the waves of the split-role kernel spend their time (diagnostic build), and what a wave that has its SIMD to
+#    itself pays for the non-VALU instructions of the row step (tools/ubench_lone_wave.hip, variants of tools/gen_fir_asm.py)
+python3 tools/stamps_fs.py 2>/dev/null > $O/stamps_fs_256.txt
+( cd tools && for v in generic straight nobranch nowait notaps nox noalign valuonly; do
+    [ -x ./ubench_lone_$v ] && ./ubench_lone_$v 400 $v; done
+  [ -x ./ubench_lone_generic ] && ./ubench_lone_generic 400 generic-unit 0
+  [ -x ./ubench_lone_straight ] && ./ubench_lone_straight 400 straight-unit 0 ) > $O/ubench_lone_wave.txt 2>&1
 # 10. two ranks on one device (rehearsal of the multi-rank bench path under gloo)
 $B --gpus 2 --steps 20 --warmup 3 > $O/bench_2ranks_one_device.json 2> $O/bench_2ranks.err
-./tools/ubench_bank 0.3 > $O/ubench_bank.txt 2>&1
 echo collected

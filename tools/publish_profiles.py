@@ -48,7 +48,9 @@ for rel, name in [("bench_default.json", "bench.json"), ("bench_300.json", "benc
                   ("stream_hour.json", "stream_hour.json"), ("stream_hour_regen.json", "stream_hour_regen.json"),
                   ("prof_stream/bench_kernel_stats.csv", "kernel_stats_stream.csv"), ("stream_forcepg.json", "stream_forcepg_nccl_world1.json"),
                   ("prof_share32/bench_kernel_stats.csv", "kernel_stats_32sources.csv"),
-                  ("ab_noeval.txt", "ab_no_chunk_ir_evaluation.txt"), ("ab_ir_sharing.txt", "ab_ir_sharing.txt")]:
+                  ("ab_noeval.txt", "ab_no_chunk_ir_evaluation.txt"), ("ab_ir_sharing.txt", "ab_ir_sharing.txt"),
+                  ("ab_split_roles.txt", "ab_split_roles.txt"), ("stamps_fs_256.txt", "stamps_fs_256sources.txt"),
+                  ("ubench_lone_wave.txt", "ubench_lone_wave.txt")]:
     copy(rel, name)
 
 # per-rank shares: one table
@@ -77,17 +79,21 @@ write = filter_counters("pmc_WRITE_SIZE/pmc_counter_collection.csv", "pmc_WRITE_
 for sq in ("pmc_SQ", "pmc_SQ2"):
     p = os.path.join(SRC, sq, "pmc_counter_collection.csv")
     if os.path.exists(p):
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sq_summary.py"), p, "bas_render_fz"],
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sq_summary.py"), p, "bas_render_f"],     # (fz: two workgroups per CU; fs: split roles)
                              capture_output=True, text=True).stdout
         open(os.path.join(DST, TAG + sq + "_fz_kernel_summary.txt"), "w").write(out)
 
-fz = [k for k in fetch if "bas_render_fz_kernel" in k]
-if fz and any("bas_render_fz_kernel" in k for k in write):
+def is_fir(k):
+    return "bas_render_fz_kernel" in k or "bas_render_fs_kernel" in k
+
+
+fz = [k for k in fetch if is_fir(k)]
+if fz and any(is_fir(k) for k in write):
     kf = fz[0]
-    kw = [k for k in write if "bas_render_fz_kernel" in k][0]
+    kw = [k for k in write if is_fir(k)][0]
     f_kb = sum(fetch[kf]["FETCH_SIZE"]) / len(fetch[kf]["FETCH_SIZE"])
     w_kb = sum(write[kw]["WRITE_SIZE"]) / len(write[kw]["WRITE_SIZE"])
-    rec = {"workload": "256x441000@K512S32L128", "fused": True, "kernel": "bas_render_fz_kernel<4>",
+    rec = {"workload": "256x441000@K512S32L128", "fused": True, "kernel": kf.split("(")[0].replace("void ", ""),
            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/" + TAG + "pmc_FETCH_SIZE.csv, "
                      + TAG + "pmc_WRITE_SIZE.csv), mean over the dispatches of python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline",
            "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb,
