@@ -199,6 +199,7 @@ U_GE, U_GO, U_GS = 210, 214, 218
 U_AL = 222
 U_LAST = 223
 U_STEPS = ((4, 8), (0, 8), (0, 8), (0, 8), (0, 4))
+ONE_WAIT = True
 
 
 def gen_unit(xr_stride):
@@ -213,11 +214,11 @@ def gen_unit(xr_stride):
         emit(line)
         queue.append(tag)
 
-    def wait_for(tag):
-        """LDS reads return in order: wait until no read with this tag is in flight"""
-        if tag not in queue:
+    def wait_for(*tags):
+        """LDS reads return in order: wait until no read with one of these tags is in flight"""
+        if not any(t in tags for t in queue):
             return
-        last = max(k for k, t in enumerate(queue) if t == tag)
+        last = max(k for k, t in enumerate(queue) if t in tags)
         n = len(queue) - 1 - last
         assert n <= 15
         emit(f"s_waitcnt lgkmcnt({n})")
@@ -275,7 +276,15 @@ def gen_unit(xr_stride):
             emit(f"v_mov_b32_e64 v{U_AL}, %[al{r}]")
         last_of_step = i == U_STEPS[r][1] - 1
         for h in range(2):
-            wait_for(f"t{r}.{i}.{h}")
+            if ONE_WAIT:
+                # ONE wait per octet, in its middle: for the octet's second half (read a whole octet ago) and the NEXT octet's
+                # first half (read half an octet ago, behind the forming of this octet's first half)
+                if h == 1:
+                    wait_for(f"t{r}.{i}.1", *([f"t{nxt[0]}.{nxt[1]}.0"] if nxt else []))
+                elif n == 0:
+                    wait_for(f"t{r}.{i}.0")
+            else:
+                wait_for(f"t{r}.{i}.{h}")
             form(h)
             if h == 0 and last_of_step and r + 1 < len(U_STEPS):
                 load_x(r + 1)                                   # (in front of the next octet's taps: it is needed first)
@@ -310,7 +319,8 @@ def main():
     check = "--check" in sys.argv[1:]                           # compare with the committed file instead of writing it
     # diagnostic variants (wrong results; tools/ubench_lone_wave.hip): --nowait no waits for the LDS reads, --nobranch no octet
     # masks (all live), --notaps no tap reads, --noalign no alignment padding, --nox no x-row reads; --out=FILE
-    global NOWAIT, NOBRANCH, NOTAPS, NOALIGN, NOX, OUT, GENERIC_ONLY
+    global NOWAIT, NOBRANCH, NOTAPS, NOALIGN, NOX, OUT, GENERIC_ONLY, ONE_WAIT
+    ONE_WAIT = "--two-waits" not in sys.argv[1:]                # (A/B: the unit block with a wait in front of every half octet)
     GENERIC_ONLY = "--generic" in sys.argv[1:]                  # (A/B: the round-3 block before the straight-line variants)
     NOWAIT, NOBRANCH, NOTAPS = ("--" + k in sys.argv[1:] for k in ("nowait", "nobranch", "notaps"))
     NOALIGN, NOX = ("--" + k in sys.argv[1:] for k in ("noalign", "nox"))
