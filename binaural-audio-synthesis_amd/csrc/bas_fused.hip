@@ -749,7 +749,10 @@ extern "C" int bas_render_fused_supported(int n_src, long T_in, int K, int S, in
 extern "C" const char *bas_render_fused_kernel_name(int n_src, long T_in, int K, int S, int L) {
     const FzPlan p = fz_plan(n_src, T_in, K, S, L);
     if (!p.nw) return "";
-    if (p.split) return FS_UNIT_BLOCK_DEFAULT && ((L + 7) & ~7) == RT_SEG ? "bas_render_fs_kernel<1>" : "bas_render_fs_kernel<0>";
+    if (p.split) {
+        const int u = bas_fs_unit_len((L + 7) & ~7);
+        return u == 128 ? "bas_render_fs_kernel<128>" : u == 104 ? "bas_render_fs_kernel<104>" : "bas_render_fs_kernel<0>";
+    }
     return p.honly ? "bas_render_fz_kernel<4,1>" : p.nw == 4 ? "bas_render_fz_kernel<4,0>" : "bas_render_fz_kernel<1,0>";
 }
 

@@ -28,10 +28,11 @@ __device__ unsigned long long bas_fs_stamps[1024 * 8 * 8];
 #define FS_NOW() 0ull
 #endif
 
-// UNIT: every unit is one whole 128-tap segment (L = 121 .. 128): its five row steps run as ONE assembly block.  (A template
-// parameter, not a branch: with both assembly statements in one loop the compiler keeps the accumulators elsewhere and copies
-// all 98 into and out of the pinned registers around every block.)
-template <bool UNIT>
+// UNITLEN = 128 / 104: every unit is one whole segment of that many taps (L = 121 .. 128; L = 97 .. 104 - the reference's
+// default samples_to_keep is 100, apply_hrtf.py:595) and its five row steps run as ONE assembly block; 0: per-step blocks.
+// (A template parameter, not a branch: with both assembly statements in one loop the compiler keeps the accumulators
+// elsewhere and copies all 98 into and out of the pinned registers around every block.)
+template <int UNITLEN>
 __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
     FzArgs A, const float *__restrict__ x,                   // [n_src] rows of T_in floats, stride A.x_stride
     float *__restrict__ slab,                                // [n_wg][parts_per_wg][2][tile]
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                 if (r >= A.S) q += 1;
                 return (float)(q * A.S) * A.invK;
             };
-            if constexpr (UNIT) {                            // a whole 128-tap segment: five row steps in one block
+            if constexpr (UNITLEN != 0) {                    // a whole segment of UNITLEN taps: its five row steps in one block
                 unsigned tapv[5];
                 float alv[5];
 #pragma unroll
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                         sl -= 1;
                     }
                 }
-                ffa_unit_asm<XR>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv);
+                ffa_unit_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv);
             } else {
 #pragma unroll 1
                 for (int rp = 0; rp <= halo; ++rp) {             // input rows rho' = 0..halo above/at the lane's output row
@@ -464,6 +465,10 @@ extern "C" int bas_debug_read_fs_stamps(unsigned long long *host, size_t count) 
 }
 #endif
 
+int bas_fs_unit_len(int Lp) {                               // segment lengths bas_fir_asm.inc holds a unit block for
+    return FS_UNIT_BLOCK && (Lp == 128 || Lp == 104) ? Lp : 0;
+}
+
 size_t bas_fs_lds_bytes(int nslots) {
     const int rows = 8192 / 32 + HD_HALO;
     return (size_t)(2 * (8 * (rows + 1) * 4 + ((nslots * HD_SLOT + 3) & ~3)) + 4 * BAS_FS_MAXEV * 2 * BAS_PLANS_WORDS + 4 * 64 * 4 + 4) *
@@ -473,8 +478,8 @@ size_t bas_fs_lds_bytes(int nslots) {
 hipError_t bas_fs_launch(const FzArgs &A, const float *x, float *slab, const float *packed, const unsigned *plans, float *y,
                          unsigned int *peak_bits, int n_wg, size_t lds_bytes, hipStream_t st, hipEvent_t eb, hipEvent_t ee) {
     typedef void (*fs_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
-    const bool unit = FS_UNIT_BLOCK && A.Lp == RT_SEG;
-    const fs_fn fn = unit ? bas_render_fs_kernel<true> : bas_render_fs_kernel<false>;
+    const fs_fn fn = bas_fs_unit_len(A.Lp) == 128 ? bas_render_fs_kernel<128> : bas_fs_unit_len(A.Lp) == 104 ? bas_render_fs_kernel<104>
+                                                                                                              : bas_render_fs_kernel<0>;
     hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
     if (e != hipSuccess) return e;
     if (eb) (void)hipEventRecord(eb, st);

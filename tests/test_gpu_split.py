@@ -46,7 +46,8 @@ def _plan_code(lib, n_src, in_length, k, s, l):
     (3, 30000, 512, 32, 128),      # one unit per workgroup, every unit one whole 128-tap segment (the unit block)
     (40, 60000, 512, 32, 128),     # 320 units on 160 workgroups: two units each through the two LDS buffers
     (47, 70000, 512, 32, 121),     # L rounded up to 128 taps: the unit block with zero taps at the end
-    (5, 40000, 512, 32, 100),      # 104 taps: per-step blocks, masks 0xf0 0xff 0xff 0x1f 0x01
+    (5, 40000, 512, 32, 100),      # 104 taps (the reference's default length): the unit block of 26 octets
+    (44, 70000, 512, 32, 90),      # 96 taps: per-step blocks, masks 0xf0 0xff 0xff 0x0f, two units per workgroup
     (3, 30000, 512, 32, 300),      # three tap segments (128 + 128 + 48)
     (2, 50000, 1024, 64, 128),     # longer chunks: fewer slots
     (4, 30000, 576, 96, 128),      # subchunk size not a power of two

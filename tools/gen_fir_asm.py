@@ -198,11 +198,20 @@ U_T = (178, 194)
 U_GE, U_GO, U_GS = 210, 214, 218
 U_AL = 222
 U_LAST = 223
-U_STEPS = ((4, 8), (0, 8), (0, 8), (0, 8), (0, 4))
+U_LSEGS = (128, 104)            # segment lengths with a unit block: L = 121 .. 128, and 97 .. 104 (the reference's default is 100)
 ONE_WAIT = True
 
 
-def gen_unit(xr_stride):
+def unit_steps(lseg):
+    """live octets [lo, hi) of the row steps rp = 0 .. halo of a segment of lseg taps (a multiple of 8): octet i of step rp
+    holds taps 32 rp - 32 + 8 i .. + 7"""
+    halo = (lseg + 31) >> 5
+    return tuple((max(0, 4 - 4 * r), min(8, (lseg + 32 - 32 * r) >> 3)) for r in range(halo + 1))
+
+
+def gen_unit(xr_stride, lseg):
+    U_STEPS = unit_steps(lseg)
+    halo = len(U_STEPS) - 1
     L = []
     emit = L.append
     queue = []                                                  # tags of the LDS reads in flight, oldest first
@@ -228,7 +237,7 @@ def gen_unit(xr_stride):
     def load_x(r):
         xb = U_XA if r % 2 == 0 else U_XB
         for c in range(8):
-            issue(f"x{r}", f"ds_read_b128 {quad(xb + 4 * c)}, %[xrow] offset:{(4 - r) * 16 + c * xr_stride * 16}")
+            issue(f"x{r}", f"ds_read_b128 {quad(xb + 4 * c)}, %[xrow] offset:{(halo - r) * 16 + c * xr_stride * 16}")
 
     def load_taps(r, i, h):
         for j in range(4):
@@ -295,15 +304,18 @@ def gen_unit(xr_stride):
     return L
 
 
-UNIT_FUNC = """
-// One (tile, source) unit of a 128-tap segment in one block (see tools/gen_fir_asm.py: gen_unit): {n_fma} v_pk_fma_f32,
-// {n_ds} ds_read_b128, {n_wait} waits.  xrow4 = LDS address of the lane's x row of step 4 (the lowest: step r reads 16 (4 - r)
-// bytes above); tap[r], al[r] = tap row address and crossfade weight of step r.
-template <int XR>
+UNIT_DECL = """
+template <int XR, int LSEG>
 __device__ __forceinline__ void ffa_unit_asm(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
                                               const unsigned (&tap)[5], const float (&al)[5]);
+"""
+
+UNIT_FUNC = """
+// One (tile, source) unit of a {lseg}-tap segment in one block (see tools/gen_fir_asm.py: gen_unit): {n_fma} v_pk_fma_f32,
+// {n_ds} ds_read_b128, {n_wait} waits.  xrow4 = LDS address of the lane's x row of step 4 (the lowest: step r reads 16 (4 - r)
+// bytes above); tap[r], al[r] = tap row address and crossfade weight of step r.
 template <>
-__device__ __forceinline__ void ffa_unit_asm<{xr}>(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
+__device__ __forceinline__ void ffa_unit_asm<{xr}, {lseg}>(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
                                               const unsigned (&tap)[5], const float (&al)[5]) {{
     asm volatile(
 {body}
@@ -338,8 +350,10 @@ def main():
             text = HEAD.format(n_fma=n_fma, xrs=" ".join(str(x) for x in xrs))
         text += FUNC.format(xr=xr, body=body, clob=clob)
     if 261 in xrs and not GENERIC_ONLY:
-        ul = gen_unit(261)
-        text += UNIT_FUNC.format(xr=261, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
+        text += UNIT_DECL
+    for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY else ()):
+        ul = gen_unit(261, lseg)
+        text += UNIT_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
                                  clob=", ".join(f'"v{r}"' for r in range(U_XA, U_LAST + 1)),
                                  n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
                                  n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),

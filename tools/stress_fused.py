@@ -53,7 +53,7 @@ for case in range(cases):
         import ctypes
         lib.bas_debug_fused_plan.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         code = lib.bas_debug_fused_plan(n_src, in_length, k, s, l)
-        kind = ("split-unit" if (l + 7) // 8 * 8 == 128 else "split") if code & 32 else ("h-only" if code & 16 else f"tile{2048 * (code & 15)}")
+        kind = ("split-unit" if (l + 7) // 8 * 8 in (128, 104) else "split") if code & 32 else ("h-only" if code & 16 else f"tile{2048 * (code & 15)}")
     seen[kind] = seen.get(kind, 0) + 1
     print(f"case {case:3d} L={l:4d} K={k:5d} S={s:4d} n_src={n_src:3d} n={n:6d} {kind} rel err {err:.2e}", flush=True)
     assert got.shape == want.shape and err < 1e-5, "PARITY FAILURE"
