@@ -116,6 +116,29 @@ def test_diagnostic_build_is_separate_and_only_it_reads_the_environment():
     assert b"BAS_FORCE_KERNEL" in open(hip.DIAG_LIB_PATH, "rb").read()
 
 
+def test_which_fused_kernel_a_shape_gets():
+    """bas_render_fused_kernel_name is host logic (the plan of a shape: no launch, no GPU needed - without a device the
+    library plans for MI355X's 256 CUs).  BASELINE config 4 and its per-rank shares run the split-role kernel, with the
+    unit block for the segment lengths it exists for; few units per CU, chunk sizes below ~448 and K = 448 (20 chunk slots
+    do not fit LDS twice) keep the kernel with two workgroups per CU; S < 32 and tiny chunks are not fused at all."""
+    lib = bas._hip.lib()
+    t = 441344
+    name = lambda *a: lib.bas_render_fused_kernel_name(*a).decode()
+    assert name(256, t, 512, 32, 128) == "bas_render_fs_kernel<128>"
+    assert name(32, t, 512, 32, 128) == "bas_render_fs_kernel<128>"            # the N = 8 share of the scene
+    assert name(256, t, 512, 32, 121) == "bas_render_fs_kernel<128>"
+    assert name(256, t, 512, 32, 100) == "bas_render_fs_kernel<104>"           # the reference's default samples_to_keep
+    assert name(256, t, 512, 32, 90) == "bas_render_fs_kernel<0>"
+    assert name(256, t, 512, 32, 300) == "bas_render_fs_kernel<0>"             # three tap segments
+    assert name(1024, 262656, 512, 32, 128) == "bas_render_fs_kernel<128>"     # a block of BASELINE config 5
+    assert name(8, t, 512, 32, 128) == "bas_render_fz_kernel<1,0>"             # 432 units: tiles of 2048
+    assert name(1, t, 512, 32, 128) == "bas_render_fz_kernel<1,0>"
+    assert name(256, t, 448, 32, 128) == "bas_render_fz_kernel<4,0>"
+    assert name(256, t, 256, 32, 128) == "bas_render_fz_kernel<4,1>"
+    for shape in ((256, t, 64, 32, 128), (256, t, 512, 16, 128)):
+        assert name(*shape) == "" and lib.bas_render_fused_supported(*shape) == 0
+
+
 def test_small_upsampling_factor_is_refused_by_the_planned_entry_points():
     """the read plans step through phase planes assuming U >= 4; smaller factors must be an error
     there (bas_interp2d_f32 serves them with its plain kernel), not silent garbage.  Argument checks run before
