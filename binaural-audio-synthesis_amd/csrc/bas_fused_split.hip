@@ -1,17 +1,19 @@
 // a6 + a7 + a8 in one kernel (gfx950), split roles: the same arithmetic as bas_render_fz_kernel<4, false> (bas_fused.hip;
 // interpolate_2d of every chunk IR a tile needs apply_hrtf.py:219-279, crossfade :442-443, FIR :445-446, overlap-add and
-// mix :450-453), same tiles, same order of accumulation - bit-identical output - but ONE workgroup of eight waves per CU:
+// mix :450-453), same tiles, same order of accumulation inside a unit (the partial sums in the slabs group the sources
+// differently: equal to that kernel's output up to float32 summation order) - but ONE workgroup of eight waves per CU:
 //
 //   waves 4-7 ("stagers")  fetch the x window and the read plans of unit u + 1, write the x image and evaluate the 18 chunk
-//                          IRs into LDS buffer (u + 1) & 1 - latency-bound work that issues ~630 vector instructions;
-//   waves 0-3 ("filters")  run the row steps of unit u on buffer u & 1 - 3 600 packed FMAs per lane, no memory access but LDS;
+//                          IRs into LDS buffer (u + 1) & 1 - latency-bound work that issues ~500 vector instructions;
+//   waves 0-3 ("filters")  run the row steps of unit u on buffer u & 1 - 3 600 vector instructions per lane, no memory access but LDS;
 //   one s_barrier per unit hands the finished buffer over and the drained one back.
 //
 // Why: with two identical workgroups per CU (bas_fused.hip) a SIMD holds one wave of each, and the VALU idles whenever both
 // are in their staging phases at once - 21-23 % of the time, and neither start offsets, clock slots nor priorities keep the two
 // in anti-phase.  Here every SIMD holds one stager and one filter by construction: the staging of the next
-// unit always runs under the FIR of the current one, and the stager (no accumulators, no row-step operands) has the registers
-// to keep more table reads in flight.  The price is LDS: two (x image, taps) buffers = 137 KB + plans, one workgroup per CU.
+// unit always runs under the FIR of the current one, and the filter (no staging state in its registers) can afford a row-step
+// block with 126 operand registers (bas_fir_asm.inc: ffa_unit_asm).  The price is LDS: two (x image, taps) buffers = 137 KB +
+// plans, one workgroup per CU; and a wave alone on its SIMD pays ~6 clocks for every LDS read and wait.
 // No MFMA: this is a 1-D FIR (BASELINE.json north_star).
 #include "bas_fused.h"
 
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                 }
                 if (need_next) {                             // (uniform) IR slot_b comes from the next wave's LDS copy
                     int spins = 0;                           // it stored that IR first thing: normally already there
-                    while (__builtin_amdgcn_readfirstlane(flags[wv + 1]) != pass_id && ++spins < (1 << 22))
+                    while ((unsigned)__builtin_amdgcn_readfirstlane(flags[wv + 1]) != pass_id && ++spins < (1 << 22))
                         __builtin_amdgcn_s_sleep(1);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     const f32x4 nx = bnd[(wv + 1) * 64 + lane];
