@@ -67,8 +67,11 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #define FZ_FFA 1                // row step as a 2-parallel fast FIR (bas_fir.h: 3/4 of the FMAs); 0: direct form
 #endif
 #ifndef FZ_SPLIT
-#define FZ_SPLIT FZ_ASM            // scenes with at least three (tile, source) units per CU: the split-role kernel (bas_fused_split.hip)
+#define FZ_SPLIT FZ_ASM            // scenes with more than one (tile of 8192, source) unit per CU: the split-role kernel (bas_fused_split.hip)
 #endif
+#ifndef FZ_SPLIT_MIN_UNITS
+#define FZ_SPLIT_MIN_UNITS 1    // ... from MORE than this many units per CU on: some workgroup then has two units and the second one's staging
+#endif                          // runs under the first one's FIR (profiles/r03b_ab_split_threshold.txt: 5-9 sources -3 .. -5 %, 10-14 -22 %)
 #ifndef FZ_PREFETCH
 #define FZ_PREFETCH 1           // the x window and the read plans of pass i + 1 are requested in front of the FIR phase of pass i and
 #endif                          // travel under it (44 registers per lane held across the row steps); 0: requested at the pass's top
@@ -711,10 +714,10 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         long slots = wg_per_cu * cus;
         const long n_tiles = (T_out + 2048L * nw - 1) / (2048L * nw);
         const long units = n_tiles * n_src;
-        // split roles (one workgroup per CU, the staging of unit u + 1 under the FIR of unit u): worth it from three units per
-        // workgroup on (the first unit's staging is exposed); needs two (x image, taps) buffers in LDS
+        // split roles (one workgroup per CU, the staging of unit u + 1 under the FIR of unit u): worth it as soon as some
+        // workgroup has two units (the first unit's staging is exposed); needs two (x image, taps) buffers in LDS
         const bool split_fits = FZ_SPLIT && nw == 4 && wg_per_cu == 2 && bas_fs_lds_bytes(nslots) <= 160 * 1024;
-        bool split = split_fits && units >= 3L * cus;
+        bool split = split_fits && units > (long)FZ_SPLIT_MIN_UNITS * cus;
 #ifdef BAS_DIAG
         if (getenv("BAS_FZ_SPLIT")) split = split_fits && atoi(getenv("BAS_FZ_SPLIT")) != 0;   // (1: also for small scenes)
 #endif

@@ -77,13 +77,13 @@ def test_split_kernel_vs_oracle_small_scenes(monkeypatch, n_src, n, k, s, l):
 
 
 def test_shipped_library_picks_the_split_kernel_for_big_scenes():
-    """48 sources x 140 000 samples = 864 (tile, source) units >= 3 per CU: the shipped library runs the split-role kernel
-    (the diagnostic build, which plans the same way, says so), three to four units per workgroup; vs the oracle."""
+    """48 sources x 140 000 samples = 864 (tile, source) units, more than one per CU: the shipped library runs the split-role
+    kernel (the diagnostic build, which plans the same way, says so), three to four units per workgroup; vs the oracle."""
     n_src, n, k, s, l = 48, 140000, 512, 32, 128
     h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, seed=50)
     with bas._hip.use_library(bas._hip.DIAG_LIB_PATH) as lib:
         assert _plan_code(lib, n_src, in_length, k, s, l) & 32
-        assert not _plan_code(lib, 8, in_length, k, s, l) & 32          # 144 units: not worth it
+        assert not _plan_code(lib, 8, in_length, k, s, l) & 32          # 144 units: no workgroup would have a second one
     d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
     got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none").cpu().numpy()
     want = _oracle(h, sigs, elev, azim, k, s)

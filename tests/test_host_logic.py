@@ -131,7 +131,8 @@ def test_which_fused_kernel_a_shape_gets():
     assert name(256, t, 512, 32, 90) == "bas_render_fs_kernel<0>"
     assert name(256, t, 512, 32, 300) == "bas_render_fs_kernel<0>"             # three tap segments
     assert name(1024, 262656, 512, 32, 128) == "bas_render_fs_kernel<128>"     # a block of BASELINE config 5
-    assert name(8, t, 512, 32, 128) == "bas_render_fz_kernel<1,0>"             # 432 units: tiles of 2048
+    assert name(8, t, 512, 32, 128) == "bas_render_fs_kernel<128>"             # 432 units: some workgroups get two
+    assert name(4, t, 512, 32, 128) == "bas_render_fz_kernel<1,0>"             # 216 units: tiles of 2048
     assert name(1, t, 512, 32, 128) == "bas_render_fz_kernel<1,0>"
     assert name(256, t, 448, 32, 128) == "bas_render_fz_kernel<4,0>"
     assert name(256, t, 256, 32, 128) == "bas_render_fz_kernel<4,1>"

@@ -3,7 +3,7 @@
 448, direct output, slab reduce, wide reduce, several tap segments) against the oracle on the adversarial table: random IR lengths, chunk / subchunk sizes,
 source counts and signal lengths, random (not smooth) trajectories.   python tools/stress_fused.py [cases] [seed] [split]
 "split": through the diagnostic build with BAS_FZ_SPLIT=1, which gives every scene with at least one (tile of 8192, source) unit
-per CU the split-role kernel (bas_fused_split.hip; the shipped library asks for three units per CU)."""
+per CU the split-role kernel (bas_fused_split.hip; the shipped library asks for more than one)."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
