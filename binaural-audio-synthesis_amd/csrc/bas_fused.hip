@@ -69,6 +69,9 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #ifndef FZ_SPLIT
 #define FZ_SPLIT FZ_ASM            // scenes with more than one (tile of 8192, source) unit per CU: the split-role kernel (bas_fused_split.hip)
 #endif
+#ifndef FZ_QUAD
+#define FZ_QUAD FZ_ASM             // scenes of at most two (tile of 2048, source) units per workgroup slot: four waves per tile (bas_fused_quad.hip)
+#endif
 #ifndef FZ_SPLIT_MIN_UNITS
 #define FZ_SPLIT_MIN_UNITS 1    // ... from MORE than this many units per CU on: some workgroup then has two units and the second one's staging
 #endif                          // runs under the first one's FIR (profiles/r03b_ab_split_threshold.txt: 5-9 sources -3 .. -5 %, 10-14 -22 %)
@@ -596,6 +599,7 @@ extern "C" int bas_debug_read_fz_stamps(unsigned long long *host, size_t count) 
 struct FzPlan {
     int nw;                    // waves per workgroup: 4 or 1 (0: shape not served)
     int split;                 // one workgroup of 4 filter + 4 stager waves per CU (bas_fused_split.hip)
+    int quad;                  // four waves per tile of 2048, the row steps dealt over them (bas_fused_quad.hip)
     int honly;                 // LDS rows hold (h_L, h_R) only (chunk sizes below ~448)
     int tile, nslots, spw;
     long n_tiles, units_total;
@@ -695,6 +699,14 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         if (force_nw && atoi(force_nw) != nw) continue;
 #endif
         const long n_tiles_nw = (T_out + 2048L * nw - 1) / (2048L * nw);
+#ifdef BAS_DIAG
+        if (nw == 4 && !force_nw) {
+#else
+        if (nw == 4) {                                       // short signals (real-time blocks): a tile of 8192 that is mostly past the
+#endif
+            const long n1 = (T_out + 2047) / 2048;           // end of the output costs as much as a full one - narrow tiles then
+            if (4 * T_out * n1 * 2048 < 3 * T_out * n_tiles_nw * 8192) continue;   // useful fraction below 3/4 of the narrow tiles'
+        }
         const int nslots = fz_slots_exact(nw, K, (L + 7) & ~7, n_tiles_nw);
         const int maxev = nw == 4 ? 6 : 7;
         const int spw = (nslots + nw - 1) / nw;                 // (h-only rows only; the (h0, d) path deals nslots + 1 IRs)
@@ -722,6 +734,19 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         if (getenv("BAS_FZ_SPLIT")) split = split_fits && atoi(getenv("BAS_FZ_SPLIT")) != 0;   // (1: also for small scenes)
 #endif
         if (split) slots = cus;
+        // four waves per tile of 2048 (staging and row steps dealt over them: a unit takes a third of the one-wave kernel's
+        // time, a CU holds two such workgroups instead of eight one-wave ones): for scenes whose units fit in two rounds
+        bool quad = false;
+        size_t quad_lds = 0;
+        if (FZ_QUAD && nw == 1 && (nslots + 1 + 3) / 4 <= BAS_FQ_MAXEV) {
+            quad_lds = bas_fq_lds_bytes(nslots);
+            const long per_cu = quad_lds * 2 <= 160 * 1024 ? 2 : quad_lds <= 160 * 1024 ? 1 : 0;
+            quad = per_cu > 0 && units <= 2 * per_cu * cus;
+#ifdef BAS_DIAG
+            if (getenv("BAS_FZ_QUAD")) quad = per_cu > 0 && atoi(getenv("BAS_FZ_QUAD")) != 0;
+#endif
+            if (quad) slots = per_cu * cus;
+        }
 #ifdef BAS_DIAG
         if (units < slots && nw > 1 && !force_nw) continue;
 #else
@@ -729,6 +754,7 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
 #endif
         p.nw = nw;
         p.split = split ? 1 : 0;
+        p.quad = quad ? 1 : 0;
         p.tile = 2048 * nw;
         p.nslots = nslots;
         p.spw = spw;
@@ -738,7 +764,7 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
         p.units_per_wg = (int)((units + wg - 1) / wg);
         p.n_wg = (int)((units + p.units_per_wg - 1) / p.units_per_wg);
         p.parts_per_wg = (p.units_per_wg + n_src - 2) / n_src + 1;
-        p.lds_bytes = split ? bas_fs_lds_bytes(nslots) : lds;
+        p.lds_bytes = split ? bas_fs_lds_bytes(nslots) : quad ? quad_lds : lds;
         p.slab_bytes = (size_t)p.n_wg * p.parts_per_wg * 2 * p.tile * sizeof(float);
         return p;
     }
@@ -756,15 +782,16 @@ extern "C" const char *bas_render_fused_kernel_name(int n_src, long T_in, int K,
         const int u = bas_fs_unit_len((L + 7) & ~7);
         return u == 128 ? "bas_render_fs_kernel<128>" : u == 104 ? "bas_render_fs_kernel<104>" : "bas_render_fs_kernel<0>";
     }
+    if (p.quad) return "bas_render_fq_kernel";
     return p.honly ? "bas_render_fz_kernel<4,1>" : p.nw == 4 ? "bas_render_fz_kernel<4,0>" : "bas_render_fz_kernel<1,0>";
 }
 
 #ifdef BAS_DIAG
 // diagnostic build only (tests, tools/stress_fused.py): which kernel a shape gets - waves per workgroup | h-only rows << 4 |
-// split roles << 5 (0: not served)
+// split roles << 5 | four waves per tile of 2048 << 6 (0: not served)
 extern "C" int bas_debug_fused_plan(int n_src, long T_in, int K, int S, int L) {
     const FzPlan p = fz_plan(n_src, T_in, K, S, L);
-    return p.nw | (p.honly << 4) | (p.split << 5);
+    return p.nw | (p.honly << 4) | (p.split << 5) | (p.quad << 6);
 }
 #endif
 
@@ -840,6 +867,15 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
                                      p.lds_bytes, st, eb, ee);
         if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
         int rc = bas_check_launch("bas_render_mix_fused_f32(fs)");
+        if (rc || A.direct) return rc;
+        return bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
+                                      peak_bits, st, "bas_render_mix_fused_f32(reduce)");
+    }
+    if (p.quad) {
+        hipError_t e = bas_fq_launch(A, x, slab, packed, reinterpret_cast<const unsigned *>(plans), y, peak_bits, p.n_wg,
+                                     p.lds_bytes, st, eb, ee);
+        if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        int rc = bas_check_launch("bas_render_mix_fused_f32(fq)");
         if (rc || A.direct) return rc;
         return bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
                                       peak_bits, st, "bas_render_mix_fused_f32(reduce)");

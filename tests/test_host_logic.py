@@ -119,8 +119,8 @@ def test_diagnostic_build_is_separate_and_only_it_reads_the_environment():
 def test_which_fused_kernel_a_shape_gets():
     """bas_render_fused_kernel_name is host logic (the plan of a shape: no launch, no GPU needed - without a device the
     library plans for MI355X's 256 CUs).  BASELINE config 4 and its per-rank shares run the split-role kernel, with the
-    unit block for the segment lengths it exists for; few units per CU, chunk sizes below ~448 and K = 448 (20 chunk slots
-    do not fit LDS twice) keep the kernel with two workgroups per CU; S < 32 and tiny chunks are not fused at all."""
+    unit block for the segment lengths it exists for; scenes of at most two rounds of 2048-output tiles run four waves per
+    tile; chunk sizes below ~448 and K = 448 (20 chunk slots do not fit LDS twice) keep the kernel with two workgroups per CU; S < 32 and tiny chunks are not fused at all."""
     lib = bas._hip.lib()
     t = 441344
     name = lambda *a: lib.bas_render_fused_kernel_name(*a).decode()
@@ -132,8 +132,11 @@ def test_which_fused_kernel_a_shape_gets():
     assert name(256, t, 512, 32, 300) == "bas_render_fs_kernel<0>"             # three tap segments
     assert name(1024, 262656, 512, 32, 128) == "bas_render_fs_kernel<128>"     # a block of BASELINE config 5
     assert name(8, t, 512, 32, 128) == "bas_render_fs_kernel<128>"             # 432 units: some workgroups get two
-    assert name(4, t, 512, 32, 128) == "bas_render_fz_kernel<1,0>"             # 216 units: tiles of 2048
-    assert name(1, t, 512, 32, 128) == "bas_render_fz_kernel<1,0>"
+    assert name(4, t, 512, 32, 128) == "bas_render_fq_kernel"                  # 864 tiles of 2048: two rounds of four-wave workgroups
+    assert name(1, t, 512, 32, 128) == "bas_render_fq_kernel"                  # BASELINE configs 2 / 3
+    assert name(256, 1024, 512, 32, 128) == "bas_render_fq_kernel"             # a real-time block: 256 sources x 512 samples + halo
+    assert name(4, t, 1024, 64, 128) == "bas_render_fq_kernel"
+    assert name(2048, 1024, 512, 32, 128) == "bas_render_fz_kernel<1,0>"       # 2048 short units: eight one-wave workgroups per CU
     assert name(256, t, 448, 32, 128) == "bas_render_fz_kernel<4,0>"
     assert name(256, t, 256, 32, 128) == "bas_render_fz_kernel<4,1>"
     for shape in ((256, t, 64, 32, 128), (256, t, 512, 16, 128)):
