@@ -200,8 +200,10 @@ int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L);
 /* Name of the kernel bas_render_mix_fused_f32 launches for these operands, for profiling tools ("" when the sizes are
  * not served): "bas_render_fs_kernel<128>" / "<104>" / "<0>" - one workgroup of four filter and four stager waves per
  * CU, two LDS buffers (scenes with more than one (tile of 8192, source) unit per CU; <128>: L = 121 .. 128, <104>:
- * L = 97 .. 104: a unit's five row steps as one assembly block) - or "bas_render_fz_kernel<4,0>" / "<1,0>" / "<4,1>": two workgroups per CU in which every wave
- * stages and filters (tiles of 8192 / 2048 outputs; <4,1>: chunk sizes below ~448, h-only LDS rows). */
+ * L = 97 .. 104: a unit's five row steps as one assembly block); "bas_render_fq_kernel" - four waves per tile of 2048
+ * outputs, staging and row steps dealt over them (small scenes: one source, a handful, real-time blocks) - or
+ * "bas_render_fz_kernel<4,0>" / "<1,0>" / "<4,1>": every wave stages and filters (two workgroups of four waves per CU on
+ * tiles of 8192 outputs / eight one-wave workgroups on tiles of 2048; <4,1>: chunk sizes below ~448, h-only LDS rows). */
 const char *bas_render_fused_kernel_name(int n_src, long T_in, int K, int S, int L);
 size_t bas_render_fused_workspace_bytes(int n_src, long T_in, int K, int S, int L);
 int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed,
