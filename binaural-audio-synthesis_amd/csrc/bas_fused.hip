@@ -70,7 +70,10 @@ __device__ unsigned long long bas_fz_stamps[2048 * 4 * 8];
 #define FZ_SPLIT FZ_ASM            // scenes with more than one (tile of 8192, source) unit per CU: the split-role kernel (bas_fused_split.hip)
 #endif
 #ifndef FZ_QUAD
-#define FZ_QUAD FZ_ASM             // scenes of at most two (tile of 2048, source) units per workgroup slot: four waves per tile (bas_fused_quad.hip)
+#define FZ_QUAD FZ_ASM             // small scenes: four waves per tile of 2048 (bas_fused_quad.hip) ...
+#endif
+#ifndef FZ_QUAD_ROUNDS
+#define FZ_QUAD_ROUNDS 3           // ... whose tiles fit in this many rounds of 2 workgroups per CU
 #endif
 #ifndef FZ_SPLIT_MIN_UNITS
 #define FZ_SPLIT_MIN_UNITS 1    // ... from MORE than this many units per CU on: some workgroup then has two units and the second one's staging
@@ -706,6 +709,8 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
 #endif
             const long n1 = (T_out + 2047) / 2048;           // end of the output costs as much as a full one - narrow tiles then
             if (4 * T_out * n1 * 2048 < 3 * T_out * n_tiles_nw * 8192) continue;   // useful fraction below 3/4 of the narrow tiles'
+            // small scenes: the tiles of 2048 fit in FZ_QUAD_ROUNDS rounds of four-wave workgroups (below): narrow tiles
+            if (FZ_QUAD && n1 * n_src <= (long)FZ_QUAD_ROUNDS * 2 * cus) continue;
         }
         const int nslots = fz_slots_exact(nw, K, (L + 7) & ~7, n_tiles_nw);
         const int maxev = nw == 4 ? 6 : 7;
@@ -735,13 +740,13 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
 #endif
         if (split) slots = cus;
         // four waves per tile of 2048 (staging and row steps dealt over them: a unit takes a third of the one-wave kernel's
-        // time, a CU holds two such workgroups instead of eight one-wave ones): for scenes whose units fit in two rounds
+        // time, a CU holds two such workgroups instead of eight one-wave ones): for scenes whose units fit in a few rounds
         bool quad = false;
         size_t quad_lds = 0;
         if (FZ_QUAD && nw == 1 && (nslots + 1 + 3) / 4 <= BAS_FQ_MAXEV) {
             quad_lds = bas_fq_lds_bytes(nslots);
             const long per_cu = quad_lds * 2 <= 160 * 1024 ? 2 : quad_lds <= 160 * 1024 ? 1 : 0;
-            quad = per_cu > 0 && units <= 2 * per_cu * cus;
+            quad = per_cu > 0 && units <= (long)FZ_QUAD_ROUNDS * per_cu * cus;
 #ifdef BAS_DIAG
             if (getenv("BAS_FZ_QUAD")) quad = per_cu > 0 && atoi(getenv("BAS_FZ_QUAD")) != 0;
 #endif
