@@ -21,6 +21,13 @@
 #define FZ_NT_LOADS 1
 #endif
 
+#ifndef FS_STAGER_PRIO
+#define FS_STAGER_PRIO 3        // wave priority of the stagers (latency bound: their few instructions go first) ...
+#endif
+#ifndef FS_FILTER_PRIO
+#define FS_FILTER_PRIO 0        // ... and of the filters
+#endif
+
 #ifdef BAS_STAMPS
 // Diagnostic build only (make stamps): per wave, in 10 ns ticks: [0] work of the role (staging or FIR + flush), [1] waiting
 // at the hand-over barrier, [6] lifetime, [7] units.
@@ -122,6 +129,7 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
         // =========================================================================================================
         // filters: lane = one row of 32 outputs of the tile, the mix over sources in 98 pinned registers
         // =========================================================================================================
+        if (FS_FILTER_PRIO) __builtin_amdgcn_s_setprio(FS_FILTER_PRIO);
         f32x32 accA, accB, accP;
         f32x2 accB16 = f32x2{0.f, 0.f};
 #pragma unroll
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
         // =========================================================================================================
         // stagers: x window -> column-major LDS image, read plans -> chunk IRs -> (h0, d) rows of the unit's slots
         // =========================================================================================================
-        __builtin_amdgcn_s_setprio(3);                       // latency bound: their few instructions go first
+        __builtin_amdgcn_s_setprio(FS_STAGER_PRIO);
         const __amdgpu_buffer_rsrc_t tab =
             __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packed), 0, (int)A.packed_bytes, 0x00020000);
         const unsigned L4 = 4u * (unsigned)A.L;
