@@ -398,8 +398,9 @@ def test_fused_accumulate_and_direct_output(tables, n_src, n, l):
 
 def test_fused_path_random_shapes():
     """tools/stress_fused.py: random IR lengths (1 .. 300), chunk sizes 448 .. 4096, subchunks 32 .. 256, 1 .. 47 sources,
-    signals up to 160 000 samples, random trajectories on the adversarial table - the fused kernel in both tile sizes,
-    direct output, slab and wide reduce, one to three tap segments - against the oracle's whole-signal render."""
+    signals up to 160 000 samples, random trajectories on the adversarial table - whichever fused kernel the plan picks
+    (split roles, four waves per tile, h-only rows), direct output, slab and wide reduce, one to three tap segments -
+    against the oracle's whole-signal render."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -407,7 +408,8 @@ def test_fused_path_random_shapes():
                        text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
-    assert last.startswith("worst") and "tile8192" in last and "tile2048" in last and "h-only" in last, last
+    # (the summary counts the cases by the kernel the plan picked for them)
+    assert last.startswith("worst") and "fs_kernel" in last and "fq_kernel" in last and "fz_kernel<4,1>" in last, last
 
 
 @pytest.mark.parametrize("k,s,l", [(512, 32, 128), (512, 32, 100), (256, 32, 128), (1024, 64, 128)])

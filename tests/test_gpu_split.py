@@ -99,4 +99,4 @@ def test_split_kernel_random_shapes():
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     last = r.stdout.strip().splitlines()[-1]
-    assert last.startswith("worst") and "split-unit" in last and "'split'" in last, last
+    assert last.startswith("worst") and "fs_kernel<128>" in last and "fs_kernel<0>" in last, last

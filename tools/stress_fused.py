@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised check of the fused path (bas_render_fz_kernel: tiles of 8192 and 2048, h-only rows for chunk sizes below
-448, direct output, slab reduce, wide reduce, several tap segments) against the oracle on the adversarial table: random IR lengths, chunk / subchunk sizes,
+"""Randomised check of the fused path (every kernel behind bas_render_mix_fused_f32: split roles on tiles of 8192 with and
+without the unit block, four waves per tile of 2048, one wave per tile, two workgroups per CU with (h0, d) or h-only rows;
+direct output, slab reduce, wide reduce, several tap segments) against the oracle on the adversarial table: random IR lengths, chunk / subchunk sizes,
 source counts and signal lengths, random (not smooth) trajectories.   python tools/stress_fused.py [cases] [seed] [split]
 "split": through the diagnostic build with BAS_FZ_SPLIT=1, which gives every scene with at least one (tile of 8192, source) unit
 per CU the split-role kernel (bas_fused_split.hip; the shipped library asks for more than one)."""
@@ -47,13 +48,7 @@ for case in range(cases):
     got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=True).cpu().numpy()
     err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
     worst = max(worst, err)
-    units4 = -(-(in_length + l - 1) // 8192) * n_src
-    kind = ("h-only" if k < 448 else "tile8192") if units4 >= 512 else "tile2048"
-    if force_split:                                           # (the diagnostic build says which kernel the shape got)
-        import ctypes
-        lib.bas_debug_fused_plan.argtypes = [ctypes.c_int, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int]
-        code = lib.bas_debug_fused_plan(n_src, in_length, k, s, l)
-        kind = ("split-unit" if (l + 7) // 8 * 8 in (128, 104) else "split") if code & 32 else ("h-only" if code & 16 else f"tile{2048 * (code & 15)}")
+    kind = lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode().replace("bas_render_", "")   # the kernel the plan picked
     seen[kind] = seen.get(kind, 0) + 1
     print(f"case {case:3d} L={l:4d} K={k:5d} S={s:4d} n_src={n_src:3d} n={n:6d} {kind} rel err {err:.2e}", flush=True)
     assert got.shape == want.shape and err < 1e-5, "PARITY FAILURE"
