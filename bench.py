@@ -16,9 +16,10 @@ starts - the audio AND the trajectories (elev, azim per chunk boundary, float64)
     bas_traj_params_f64        a3: angles -> (4 directions, 3 weights) per chunk boundary (sphere.py:78-121,
                                apply_hrtf.py:199-215, :261-266)
     bas_interp2d_plan_f32      delays, shift splits, folded blend weights (apply_hrtf.py:219-279)
-    bas_render_mix_fused_f32   chunk IRs from the table + time-varying FIR + overlap-add + mix + fused peak
-    [N>1: one RCCL gather of the partial mixes to rank 0 + fixed-order sum]
-    bas_scale_by_peak_f32      the peak rule (apply_hrtf.py:462-464)
+    bas_render_mix_fused_f32   chunk IRs from the table + time-varying FIR + overlap-add + mix + max|y| + the peak rule
+                               (apply_hrtf.py:462-464) in the tail of its last kernel
+    [N>1: one RCCL gather of the un-normalised partial mixes to rank 0; there bas_mix_finish_f32: fixed-order sum +
+     max|y| + peak rule in one launch]
 
 Scaling: with N > 1 the ONE scene is sharded by source over the GPUs (config 4 read literally: strong scaling,
 `value` = that scene's stereo samples per second).  The same invocation then also times the weak reading (every
@@ -57,6 +58,11 @@ def parse():
                     help="strong (default): BASELINE config 4 read literally, ONE --sources-source scene sharded "
                          "over the GPUs; weak: every GPU renders --sources sources")
     ap.add_argument("--no-extra", action="store_true", help="N > 1: skip the second (weak) measurement")
+    ap.add_argument("--root-weight", default="auto",
+                    help="strong scaling, N > 1: fraction of an equal share of the sources that rank 0 renders - it also "
+                         "receives the gather and sums the partial mixes while the others already render their next "
+                         "step (distributed.shard_sources).  auto: an equal share minus the ~15 us the receive + sum "
+                         "cost, at ~2.4 us of render per source = 6 sources' worth, spread over the other ranks; 1: equal shares")
     ap.add_argument("--settle-ms", type=float, default=400.0,
                     help="untimed steps for this many milliseconds BEFORE the --warmup steps: a cold MI355X needs ~40 ms "
                          "of load before its clock governor settles (profiles/r02_warmup_series.txt); 0 = off")
@@ -338,6 +344,17 @@ def self_launch(args):
     return r.returncode
 
 
+def root_weight(args, world):
+    """--root-weight as a number (see its help text)."""
+    if world == 1:
+        return 1.0
+    if args.root_weight == "auto":
+        if args.sources < 16 * world:                        # (toy scenes: the fixed costs are not what the split is about)
+            return 1.0
+        return max(0.5, 1.0 - 6.0 * (world - 1) / args.sources)
+    return float(args.root_weight)
+
+
 class Scene:
     """One rank's share of a scene, resident in HBM, and the step that renders it."""
 
@@ -350,7 +367,8 @@ class Scene:
         n = int(round(args.seconds * FS))
         k, s, l = args.chunk, args.subchunk, args.taps
         if scaling == "strong":                                  # one scene, sources split over the ranks
-            mine = bas.distributed.shard_sources(args.sources, world, rank)
+            self.root_weight = root_weight(args, world)
+            mine = bas.distributed.shard_sources(args.sources, world, rank, root_weight=self.root_weight)
             n_src, first_src, total_src = len(mine), mine.start, args.sources
         else:                                                    # every rank its own args.sources sources
             n_src, first_src, total_src = args.sources, rank * args.sources, args.sources * world
@@ -372,8 +390,9 @@ class Scene:
         self.idx = torch.empty((n_src * n_q, 4), dtype=torch.int32, device=dev)
         self.w = torch.empty((n_src * n_q, 3), dtype=torch.float64, device=dev)
         lib = _hip.lib()
-        self.ws = torch.empty((max(lib.bas_render_workspace_bytes(n_src, in_length, k, s, l),
-                                   lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l)),), dtype=torch.uint8, device=dev)
+        self.ws = _hip.new_workspace(max(lib.bas_render_workspace_bytes(n_src, in_length, k, s, l),
+                                         lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l)), dev)
+        self.ws_mix = _hip.new_workspace(lib.bas_mix_workspace_bytes(), dev)
         self.ws_i = torch.empty((lib.bas_interp2d_workspace_bytes(n_src * n_q),), dtype=torch.uint8, device=dev)
         self.y = torch.empty((2, t_out), dtype=torch.float32, device=dev)
         self.parts = torch.empty((world, 2, t_out), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
@@ -385,11 +404,12 @@ class Scene:
                        else lib.bas_render_kernel_name(n_src, in_length, k, s, l).decode())
         self.host_u = host_u
 
-    def render_into(self, y_buf, events):
-        """a3 -> plans -> (chunk IRs +) FIR + mix + peak, all on the current stream."""
+    def render_into(self, y_buf, events, normalize="none"):
+        """a3 -> plans -> (chunk IRs +) FIR + mix + peak [+ the peak rule in the last kernel's tail], all on the
+        current stream.  Returns the peak tensor (max|y| before the rule)."""
         bas, a = self.bas, self.args
         return bas.apply_hrtf.render_angles_device(self.x, a.chunk, a.subchunk, self.tbl, self.elev, self.azim,
-                                                   normalize="none", out=y_buf, events=events, ws=self.ws,
+                                                   normalize=normalize, out=y_buf, events=events, ws=self.ws,
                                                    ws_plans=self.ws_i, fused=self.fused, params=(self.idx, self.w))[1]
 
 
@@ -442,15 +462,12 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
     # in eager steps of its own right after the timed region (same process, same clocks)
     ev = HipEvents(args.steps) if with_events else None
 
-    def mix_on_root(parts_buf):
-        stream = _hip.current_stream(dev)
-        _hip.call("bas_mix_partials_f32", _hip.ptr(parts_buf), world, 2 * t_out, 2 * t_out, _hip.ptr(sc.y_final),
-                  _hip.ptr(sc.peak), stream)
-        _hip.call("bas_scale_by_peak_f32", _hip.ptr(sc.y_final), 2 * t_out, _hip.ptr(sc.peak), stream)
+    def mix_on_root(parts_buf):                             # fixed-order sum + max|y| + peak rule: ONE launch
+        _hip.call("bas_mix_finish_f32", _hip.ptr(parts_buf), world, 2 * t_out, 2 * t_out, _hip.ptr(sc.y_final),
+                  _hip.ptr(sc.peak), 1, _hip.ptr(sc.ws_mix), sc.ws_mix.numel(), _hip.current_stream(dev))
 
-    def render_single(y_buf, events=None):                  # the whole N = 1 step: render + peak rule
-        pk = sc.last_peak = sc.render_into(y_buf, events)
-        _hip.call("bas_scale_by_peak_f32", _hip.ptr(y_buf), 2 * t_out, _hip.ptr(pk), _hip.current_stream(dev))
+    def render_single(y_buf, events=None):                  # the whole N = 1 step: render with the peak rule in its tail
+        sc.last_peak = sc.render_into(y_buf, events, normalize="mix")
 
     # N > 1: the gather of step i travels (RCCL stream, xGMI) while step i+1 renders; y and the root's receive
     # buffer are double-buffered, the root sums step i right after it has launched step i+1's gather.  Every
@@ -608,6 +625,7 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
                 torch.cuda.synchronize(dev)
                 assert torch.equal(plain, sc.y_final), "collective path at world_size 1 differs from the plain N = 1 step"
                 print("check: collective path at world_size 1 == plain step, bit for bit", file=sys.stderr, flush=True)
+    _hip.check_status(sc.ws, dev)                             # device-side error record of the workspace (outside the timed region)
     if with_events and rank == 0 and not args.no_self_check and scaling == args.scaling:
         y_chk = sc.y_final if collective else sc.y
         if not collective or world == 1:                     # (N > 1: the root's mix holds other ranks' sources too)
@@ -746,11 +764,13 @@ def main():
                                    f"device; step = angles->parameters (a3) + read plans + "
                                    + ("fused chunk-IR evaluation/FIR/overlap-add/mix" if sc.fused_used else
                                       "chunk IRs (interp2d) + FIR/overlap-add/mix")
-                                   + f" + peak rule; {n_src} sources on this GPU, {world} GPU(s)",
+                                   + f" + peak rule (in the last kernel's tail); {n_src} sources on this GPU, {world} GPU(s)",
                        "sources_per_gpu": n_src, "scene_sources": sc.total_src, "samples_per_source": n, "chunk": k,
                        "subchunk": s, "taps": l, "out_samples": t_out, "fused": sc.fused_used,
                        "parallelism": f"sources sharded over {world} GPU(s), 1 gather per step" +
-                                      (", travelling beside the next step's render" if overlap else "")},
+                                      (", travelling beside the next step's render" if overlap else "") +
+                                      (f"; rank 0 (receives and sums) renders {sc.root_weight:.3f} of an equal share"
+                                       if world > 1 and scaling == "strong" else "")},
             "x_realtime": (n / FS) * scenes / (elapsed / args.steps),
             "source_samples_per_s": sc.total_src * in_length * args.steps / elapsed,
             "multi_gpu_status": "no N > 1 figure of this repository is hardware-measured until the driver's SCALE run: the "

@@ -44,17 +44,30 @@ SIGNATURES = {
     "bas_render_fused_kernel_name": (ctypes.c_char_p, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_fused_workspace_bytes": (_c_size_t, [_c_int, _c_long, _c_int, _c_int, _c_int]),
     "bas_render_mix_fused_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_long, _c_int,
-                                          _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_void_p,
+                                          _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                                          _c_size_t, _c_void_p]),
+    "bas_render_mix_fused_profiled_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_long, _c_int,
+                                          _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
                                           _c_size_t, _c_void_p, _c_void_p, _c_void_p]),
+    "bas_render_fused_fir_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_long, _c_int,
+                                          _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                                          _c_size_t, _c_void_p]),
+    "bas_render_fused_reduce_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_long, _c_int,
+                                          _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_int, _c_void_p, _c_int, _c_void_p,
+                                          _c_size_t, _c_void_p]),
+    "bas_render_status": (_c_int, [_c_void_p, _c_size_t, _c_void_p]),
     "bas_peak_normalize_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_int, _c_void_p]),
     "bas_scale_by_peak_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p]),
     "bas_mix_partials_f32": (_c_int, [_c_void_p, _c_int, _c_long, _c_long, _c_void_p, _c_void_p, _c_void_p]),
+    "bas_mix_workspace_bytes": (_c_size_t, []),
+    "bas_mix_finish_f32": (_c_int, [_c_void_p, _c_int, _c_long, _c_long, _c_void_p, _c_void_p, _c_int, _c_void_p, _c_size_t,
+                                    _c_void_p]),
     "bas_stream_epilogue_f32": (_c_int, [_c_void_p, _c_long, _c_int, _c_int, _c_long, _c_void_p, _c_void_p, _c_long,
                                          _c_int, _c_int, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p]),
 }
 
 _lib = None
-ABI_VERSION = 4                                                      # BAS_ABI_VERSION of include/bas.h
+ABI_VERSION = 5                                                      # BAS_ABI_VERSION of include/bas.h
 DIAG_LIB_PATH = os.path.join(_HERE, "csrc", "libbas_hip_diag.so")   # -DBAS_DIAG build: reads BAS_FORCE_KERNEL (tests only)
 
 
@@ -164,6 +177,26 @@ def on_device_of(argname_or_index):
                 return fn(*args, **kwargs)
         return wrapper
     return deco
+
+
+WS_CONTROL_BYTES = 64
+
+
+def new_workspace(nbytes, device):
+    """Scratch for the render / mix entry points (include/bas.h): uninitialised device bytes whose first 64 - the
+    library's control block (tail counters, device-side error record) - are zeroed once, here; every call leaves them
+    zero.  One workspace serves one stream at a time."""
+    import torch
+    ws = torch.empty((max(int(nbytes), WS_CONTROL_BYTES),), dtype=torch.uint8, device=device)
+    ws[:WS_CONTROL_BYTES].zero_()
+    return ws
+
+
+def check_status(ws, device):
+    """Raise BasError if a kernel that used workspace `ws` recorded a device-side error (bas_render_status: synchronises
+    the current stream of `device`; call where the caller synchronises anyway)."""
+    with on_device(device):
+        call("bas_render_status", ptr(ws), ws.numel(), current_stream(device))
 
 
 def ptr(t):

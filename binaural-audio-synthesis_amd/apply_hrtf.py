@@ -262,16 +262,22 @@ def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=Non
 
 @_hip.on_device_of("x")
 def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix", out=None, events=None,
-                         ws=None, ws_plans=None, fused=None, angles=None, n_queries=None):
+                         ws=None, ws_plans=None, fused=None, angles=None, n_queries=None, want_peak=True, check=False):
     """interpolate_2d + render for precomputed parameters: x [n_src, T_in] device float32,
     idx int32 [n_src*(n_chunks+1), 4], w float64 [.., 3] on the device.  Uses the fused kernel
     (chunk IRs evaluated inside the FIR kernel, never stored) when the sizes allow it, else
-    bas_interp2d_f32 + bas_render_mix_f32.  Returns (y [2, T_out], peak)."""
+    bas_interp2d_f32 + bas_render_mix_f32.  Returns (y [2, T_out], peak).
+    normalize="mix": the peak rule (apply_hrtf.py:462-464) inside the render call (the tail of its last kernel: no launch
+    of its own).  want_peak=False with normalize="none": max|y| is not computed at all (returns peak None; streams track
+    their own running peak).  ws: a workspace from _hip.new_workspace (zeroed control block).  check=True: ask the
+    library for device-side errors afterwards (synchronises the stream: for callers that copy the result to the host anyway)."""
     import torch
     tbl = as_device_table(tbl)
     dev = x.device
     n_src, t_in = x.shape
     lib = _hip.lib()
+    if normalize not in ("mix", "none"):
+        raise ValueError("normalize must be 'mix' or 'none'")
     if fused is None or fused:                                # default: fused wherever the kernel serves the shape
         fused = bool(lib.bas_render_fused_supported(n_src, t_in, chunksize, subchunksize, tbl.L)) and \
             tbl.upsampling >= 4 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
@@ -285,13 +291,13 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
                              normalize, out=out, events=events, ws=ws)
     t_out = t_in + tbl.L - 1
     y = out if out is not None else torch.empty((2, t_out), dtype=torch.float32, device=dev)
-    peak = torch.empty((1,), dtype=torch.float32, device=dev)
+    peak = torch.empty((1,), dtype=torch.float32, device=dev) if (want_peak or normalize == "mix") else None
     pb = lib.bas_interp2d_workspace_bytes(n_q)
     if ws_plans is None or ws_plans.numel() < pb:
         ws_plans = torch.empty((pb,), dtype=torch.uint8, device=dev)
     wb = lib.bas_render_fused_workspace_bytes(n_src, t_in, chunksize, subchunksize, tbl.L)
     if ws is None or ws.numel() < wb:
-        ws = torch.empty((wb,), dtype=torch.uint8, device=dev)
+        ws = _hip.new_workspace(wb, dev)
     stream = _hip.current_stream(dev)
     if angles is None:
         _hip.call("bas_interp2d_plan_f32", _hip.ptr(tbl.diffs), _hip.ptr(idx), _hip.ptr(w), n_q, tbl.ndir, tbl.L,
@@ -302,14 +308,14 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
         _hip.call("bas_interp2d_plan_angles_f32", _hip.ptr(tbl.diffs), _hip.ptr(e), _hip.ptr(z), n_q, ring_elev,
                   ring_start, ring_count, _hip.ptr(sphere.device_nodes(dev)), sphere.BRANCHES[branch], tbl.ndir, tbl.L,
                   tbl.upsampling, _hip.ptr(ws_plans), ws_plans.numel(), stream)
-    ev = events if events is not None else (None, None)
-    _hip.call("bas_render_mix_fused_f32", _hip.ptr(x), x.stride(0), _hip.ptr(tbl.packed), _hip.ptr(ws_plans), n_src,
-              t_in, chunksize, subchunksize, tbl.L, tbl.upsampling, tbl.ndir, _hip.ptr(y), 0, _hip.ptr(peak),
-              _hip.ptr(ws), ws.numel(), stream, ev[0], ev[1])
-    if normalize == "mix":
-        _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), 2 * t_out, _hip.ptr(peak), stream)
-    elif normalize != "none":
-        raise ValueError("normalize must be 'mix' or 'none'")
+    args = (_hip.ptr(x), x.stride(0), _hip.ptr(tbl.packed), _hip.ptr(ws_plans), n_src, t_in, chunksize, subchunksize, tbl.L,
+            tbl.upsampling, tbl.ndir, _hip.ptr(y), 0, _hip.ptr(peak), int(normalize == "mix"), _hip.ptr(ws), ws.numel(), stream)
+    if events is None:
+        _hip.call("bas_render_mix_fused_f32", *args)          # peak rule included (:462-464)
+    else:
+        _hip.call("bas_render_mix_fused_profiled_f32", *args, events[0], events[1])
+    if check:
+        _hip.check_status(ws, dev)
     return y, peak
 
 
@@ -317,14 +323,15 @@ MERGED_A3_MAX_QUERIES = 65536       # below this a3 rides inside the plan kernel
 
 
 def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize="mix", out=None, events=None,
-                         ws=None, ws_plans=None, fused=None, params=None, branch="f64"):
+                         ws=None, ws_plans=None, fused=None, params=None, branch="f64", want_peak=True, check=False):
     """The whole device side of make_signal_move_2d for trajectories that live on the GPU: x [n_src, T_in] device
     float32 (T_in % K == 0), elev / azim float64 device tensors [n_src, T_in/K + 1] (radians at t = 0, K, .., T_in).
     bas_traj_params_f64 (a3 + the elevation bracket), then render_params_device (read plans + fused FIR where the
     sizes allow it).  `params` = optional (idx [n, 4] int32, w [n, 3] float64) buffers to write the parameters
     into (no allocation per call).  Returns (y [2, T_out], peak).
-    (A single kernel for a3 + read plans was tried: every (query, ear) thread then redoes the angle arithmetic and
-    the merged kernel took 53 us against 9 + 25 us for the two.)"""
+    Batches of at most MERGED_A3_MAX_QUERIES queries run a3 inside the plan kernel (bas_interp2d_plan_angles_f32: one
+    launch less); above that both ears' threads redoing the angle arithmetic cost more than the launch (221 k queries:
+    53 us merged against 9 + 15 us)."""
     tbl = as_device_table(tbl)
     n_src, t_in = x.shape
     if elev.numel() != n_src * (t_in // chunksize + 1) or azim.numel() != elev.numel():
@@ -336,10 +343,11 @@ def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize=
         if branch not in sphere.BRANCHES:
             raise ValueError("branch must be 'f64' or 'pyfloat'")
         return render_params_device(x, chunksize, subchunksize, tbl, None, None, normalize, out=out, events=events, ws=ws,
-                                    ws_plans=ws_plans, fused=fused, angles=(elev, azim, branch), n_queries=elev.numel())
+                                    ws_plans=ws_plans, fused=fused, angles=(elev, azim, branch), n_queries=elev.numel(),
+                                    want_peak=want_peak, check=check)
     idx, w = sphere.interpolation_params_device(elev, azim, out=params, branch=branch)
     return render_params_device(x, chunksize, subchunksize, tbl, idx.reshape(-1, 4), w.reshape(-1, 3), normalize,
-                                out=out, events=events, ws=ws, ws_plans=ws_plans, fused=fused)
+                                out=out, events=events, ws=ws, ws_plans=ws_plans, fused=fused, want_peak=want_peak, check=check)
 
 
 def _params_to_device(tbl, idx, w):
@@ -449,9 +457,10 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     x[0, :n] = src.to(device=dev, dtype=torch.float32)
     if vectorized:
         y, _ = render_angles_device(x, int(chunksize), int(subchunksize), tbl, ea[0].reshape(1, -1), ea[1].reshape(1, -1),
-                                    "mix", branch=branch)
+                                    "mix", branch=branch, check=not is_tensor)
     else:
-        y, _ = render_params_device(x, int(chunksize), int(subchunksize), tbl, idx_t.reshape(-1, 4), w_t.reshape(-1, 3), "mix")
+        y, _ = render_params_device(x, int(chunksize), int(subchunksize), tbl, idx_t.reshape(-1, 4), w_t.reshape(-1, 3), "mix",
+                                    check=not is_tensor)
     if verbose:
         print(' 100.0%      ')
     out = y.t()                                                              # (out_length, 2), F-ordered like :459

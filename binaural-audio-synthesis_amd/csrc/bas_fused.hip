@@ -131,7 +131,10 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
     const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
     const long n_pass = (unit1 - unit0) * nseg;
     if (!A.direct && peak_bits && blockIdx.x == 0 && tid0 == 0) *peak_bits = 0u;   // the reduce kernel maxes into it later
-    if (n_pass <= 0) return;
+    if (n_pass <= 0) {
+        if (A.direct && A.tail_mode) bas_tail<THREADS>(fz_tail(A, y, peak_bits), 0.f);
+        return;
+    }
 
     constexpr bool USE_ASM = FZ_ASM && FZ_FFA && !HONLY;
     static_assert(!USE_ASM || XR == 261 || XR == 69, "bas_fir_asm.inc holds the row step for these x-image strides");
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
 
     const long first_tile = unit0 / A.n_src;
     float *slab_wg = slab + (long)blockIdx.x * A.parts_per_wg * 2 * TILE;
+    unsigned wmax_bits = 0u;                                 // direct output with a tail: max|y| this wave has stored (uniform)
     const unsigned prio_flip = blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u;
     const __amdgpu_buffer_rsrc_t tab =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(packed), 0, (int)A.packed_bytes, 0x00020000);
@@ -188,34 +192,11 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
 #endif
         if (A.direct) {                                      // uniform
             const long n0 = tile * TILE + 2048 * wv + 32 * lane0;       // this lane's first output
-            float lmax = 0.f;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float *ye = y + (long)e * A.T_out + n0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    f32x4 v = e == 0 ? f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x}
-                                     : f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y};
-                    const long n = n0 + 4 * i;
-                    if (n + 3 < A.T_out) {
-                        f32x4_a4 *p = reinterpret_cast<f32x4_a4 *>(ye + 4 * i);   // (the right ear starts at 4 T_out bytes)
-                        if (A.accumulate) v += *p;
-                        *p = v;
-                        lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-                    } else {
-                        const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (n + j < A.T_out) {
-                                const float r = A.accumulate ? vv[j] + ye[4 * i + j] : vv[j];
-                                ye[4 * i + j] = r;
-                                lmax = fmaxf(lmax, fabsf(r));
-                            }
-                        }
-                    }
-                }
-            }
-            if (peak_bits) {
+            const float lmax = fz_store_row_direct(acc, y, A.T_out, n0, A.accumulate, A.tail_mode != 0);
+            if (A.tail_mode) {
+                const unsigned b = fz_wave_max_bits(lmax);
+                wmax_bits = b > wmax_bits ? b : wmax_bits;
+            } else if (peak_bits) {
                 bas_wave_peak_max(lmax, peak_bits);
             }
             FZ_ACC_CLEAR();
@@ -442,7 +423,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
                     if (NW > 1 && i == 0 && wv > 0) {        // (uniform) the previous wave's last slot needs this IR
                         bnd[wv * 64 + lane] = h;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) flags[wv] = pass_id;
+                        if (lane == 0 && !fz_inject(A)) flags[wv] = pass_id;
                     }
                     // slot slot_a + i - 1 = (IR i-1, IR i - IR i-1), written once IR i is known
                     if (i > 0) {
@@ -461,11 +442,10 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
             }
             if constexpr (!HONLY && NW > 1) {
                 if (need_next) {                             // (uniform) IR slot_b comes from the next wave's LDS copy
-                    int spins = 0;                           // it stored that IR first thing: normally already there
-                    while (__builtin_amdgcn_readfirstlane(flags[wv + 1]) != pass_id && ++spins < (1 << 22))
-                        __builtin_amdgcn_s_sleep(1);
+                    const bool got = fz_wait_handover(flags + wv + 1, pass_id, A);   // it stored that IR first thing
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const f32x4 nx = bnd[(wv + 1) * 64 + lane];
+                    f32x4 nx = bnd[(wv + 1) * 64 + lane];
+                    if (!got) nx = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
                     f32x2 h0a, h0b, da, db;
                     fz_pair_ears(prev, h0a, h0b);
                     fz_pair_ears(nx - prev, da, db);
@@ -577,6 +557,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
         G = GN;
     }
     flush(open_tile);
+    if (A.direct && A.tail_mode) bas_tail<THREADS>(fz_tail(A, y, peak_bits), __uint_as_float(wmax_bits));
 #ifdef BAS_STAMPS
     if (lane0 == 0 && blockIdx.x < 2048) {
         unsigned long long *d = bas_fz_stamps + (blockIdx.x * 4 + wv) * 8;
@@ -801,54 +782,64 @@ extern "C" int bas_debug_fused_plan(int n_src, long T_in, int K, int S, int L) {
 #endif
 
 extern "C" size_t bas_render_fused_workspace_bytes(int n_src, long T_in, int K, int S, int L) {
-    return fz_plan(n_src, T_in, K, S, L).slab_bytes + 16;
+    return BAS_WS_HEAD_BYTES + fz_plan(n_src, T_in, K, S, L).slab_bytes + 16;
 }
 
-extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed, const void *plans,
-                                        int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y,
-                                        int accumulate, float *peak, void *ws, size_t ws_bytes,
-                                        bas_stream_t stream, void *ev_begin, void *ev_end) {
-    BAS_REQUIRE(y, BAS_E_NULL, "bas_render_mix_fused_f32: y is null");
+// phases: 1 = the FIR kernel (slab parts, or y itself for scenes whose tiles are each finished by one workgroup),
+// 2 = the slab reduce (+ max|y| + peak rule), 3 = both.  One implementation behind bas_render_mix_fused_f32,
+// bas_render_mix_fused_profiled_f32, bas_render_fused_fir_f32 and bas_render_fused_reduce_f32.
+static int fused_impl(const char *who, int phases, const float *x, long x_stride, const float *packed, const void *plans,
+                      int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y, int accumulate, float *peak,
+                      int normalize, void *ws, size_t ws_bytes, bas_stream_t stream, void *ev_begin, void *ev_end) {
+    BAS_REQUIRE(y, BAS_E_NULL, "%s: y is null", who);
     BAS_REQUIRE(n_src >= 0 && T_in >= 0 && K > 0 && S > 0 && L > 0 && ndir > 0, BAS_E_SHAPE,
-                "bas_render_mix_fused_f32: need n_src>=0, T_in>=0, K,S,L,ndir>0 (n_src=%d T_in=%ld K=%d S=%d L=%d)",
-                n_src, T_in, K, S, L);
-    BAS_REQUIRE(U >= BAS_PLAN_MIN_U, BAS_E_SHAPE, "bas_render_mix_fused_f32: needs an upsampling factor >= %d (U=%d)",
-                BAS_PLAN_MIN_U, U);
-    BAS_REQUIRE(K % S == 0, BAS_E_SHAPE,
-                "bas_render_mix_fused_f32: subchunksize does not divide chunksize evenly (K=%d S=%d)", K, S);
-    BAS_REQUIRE(T_in % K == 0, BAS_E_SHAPE, "bas_render_mix_fused_f32: T_in (%ld) must be a multiple of K (%d)", T_in, K);
-    BAS_REQUIRE(T_in / K < (1L << 30), BAS_E_SHAPE, "bas_render_mix_fused_f32: too many chunks");
+                "%s: need n_src>=0, T_in>=0, K,S,L,ndir>0 (n_src=%d T_in=%ld K=%d S=%d L=%d)", who, n_src, T_in, K, S, L);
+    BAS_REQUIRE(U >= BAS_PLAN_MIN_U, BAS_E_SHAPE, "%s: needs an upsampling factor >= %d (U=%d)", who, BAS_PLAN_MIN_U, U);
+    BAS_REQUIRE(K % S == 0, BAS_E_SHAPE, "%s: subchunksize does not divide chunksize evenly (K=%d S=%d)", who, K, S);
+    BAS_REQUIRE(T_in % K == 0, BAS_E_SHAPE, "%s: T_in (%ld) must be a multiple of K (%d)", who, T_in, K);
+    BAS_REQUIRE(T_in / K < (1L << 30), BAS_E_SHAPE, "%s: too many chunks", who);
     hipStream_t st = bas_stream(stream);
     const long T_out = T_in + L - 1;
     unsigned int *peak_bits = reinterpret_cast<unsigned int *>(peak);
     const bool live = n_src > 0 && T_in > 0;
     if (!live) {                                             // nothing to render: y = 0 (or untouched), peak = max|y|
+        if (!(phases & 2)) return 0;
         if (peak) {
             hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);
-            if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+            if (e != hipSuccess) return bas_fail((int)e, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
         }
         if (!accumulate) {
             hipError_t e = hipMemsetAsync(y, 0, (size_t)2 * T_out * sizeof(float), st);
-            if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+            if (e != hipSuccess) return bas_fail((int)e, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
             return 0;
         }
-        return peak ? bas_peak_normalize_f32(y, 2 * T_out, peak, 0, stream) : 0;
+        return (peak || normalize) ? bas_peak_normalize_f32(y, 2 * T_out, peak, normalize, stream) : 0;
     }
-    BAS_REQUIRE(x && packed && plans, BAS_E_NULL, "bas_render_mix_fused_f32: x, packed or plans is null");
-    BAS_REQUIRE(x_stride >= T_in, BAS_E_SHAPE, "bas_render_mix_fused_f32: x_stride < T_in");
+    BAS_REQUIRE(x && packed && plans, BAS_E_NULL, "%s: x, packed or plans is null", who);
+    BAS_REQUIRE(x_stride >= T_in, BAS_E_SHAPE, "%s: x_stride < T_in", who);
     BAS_REQUIRE(reinterpret_cast<uintptr_t>(plans) % 16 == 0 && reinterpret_cast<uintptr_t>(x) % 16 == 0 &&
                     x_stride % 4 == 0 && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
-                BAS_E_ALIGN, "bas_render_mix_fused_f32: x, plans and ws must be 16-byte aligned, x_stride a multiple of 4");
+                BAS_E_ALIGN, "%s: x, plans and ws must be 16-byte aligned, x_stride a multiple of 4", who);
     const FzPlan p = fz_plan(n_src, T_in, K, S, L);
     BAS_REQUIRE(p.nw != 0, BAS_E_SHAPE,
-                "bas_render_mix_fused_f32: sizes not served by the fused kernel (bas_render_fused_supported); use "
-                "bas_interp2d_f32 + bas_render_mix_f32");
+                "%s: sizes not served by the fused kernel (bas_render_fused_supported); use bas_interp2d_f32 + "
+                "bas_render_mix_f32", who);
     BAS_REQUIRE(p.units_total < (1L << 31) - 65536, BAS_E_SHAPE,
-                "bas_render_mix_fused_f32: %ld (tile, source) work units exceed 2^31: render in blocks", p.units_total);
-    BAS_REQUIRE(ws && ws_bytes >= p.slab_bytes, BAS_E_WORKSPACE,
-                "bas_render_mix_fused_f32: workspace of %zu bytes needed, %zu given", p.slab_bytes, ws_bytes);
+                "%s: %ld (tile, source) work units exceed 2^31: render in blocks", who, p.units_total);
+    BAS_REQUIRE(ws && ws_bytes >= BAS_WS_HEAD_BYTES + p.slab_bytes, BAS_E_WORKSPACE,
+                "%s: workspace of %zu bytes needed, %zu given", who, (size_t)BAS_WS_HEAD_BYTES + p.slab_bytes, ws_bytes);
     const size_t table_bytes = (size_t)2 * ndir * U * BAS_PLANE(L) * sizeof(float);
-    BAS_REQUIRE(table_bytes < (1ul << 31), BAS_E_SHAPE, "bas_render_mix_fused_f32: table too large");
+    BAS_REQUIRE(table_bytes < (1ul << 31), BAS_E_SHAPE, "%s: table too large", who);
+    // workspace: [control block 64 B | BAS_TAIL_MAX_WG maxima | slabs]
+    unsigned *ctl = reinterpret_cast<unsigned *>(ws);
+    float *wgpeak = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + BAS_CTL_WORDS * 4);
+    float *slab = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + BAS_WS_HEAD_BYTES);
+    float *peak_dev = peak ? peak : reinterpret_cast<float *>(ctl + 8);       // (the rule needs the peak somewhere)
+    const bool want_peak = peak != nullptr || normalize != 0;
+    const bool y_quads = reinterpret_cast<uintptr_t>(y) % 16 == 0;            // the tail rescales 16 bytes at a time
+    BasTail T = {};
+    T.ctl = ctl; T.wgpeak = wgpeak; T.y = y; T.n = 2 * T_out; T.peak = peak_dev;
+    T.normalize = normalize && y_quads ? 1 : 0;
     FzArgs A;
     A.x_stride = x_stride; A.n_src = n_src; A.T_in = T_in;
     A.K = K; A.S = S; A.L = L; A.Lp = (L + 7) & ~7; A.n_chunks = (int)(T_in / K);
@@ -858,43 +849,85 @@ extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const flo
     A.nslots = p.nslots; A.spw = p.spw;
     A.packed_bytes = (unsigned)table_bytes;
     A.direct = p.units_per_wg % n_src == 0;
-    if (peak && A.direct) {                                  // direct output: workgroups max into the peak as they finish.
-        hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);          // (slab form: the FIR kernel clears it, the
-        if (e != hipSuccess)                                                //  reduce kernel behind it takes the max)
-            return bas_fail((int)e, "bas_render_mix_fused_f32: hipMemsetAsync: %s", hipGetErrorString(e));
-    }
     A.accumulate = accumulate;
     A.T_out = T_out;
-    float *slab = reinterpret_cast<float *>(ws);
+    A.ctl = ctl;
+    A.tail_mode = 0;
+#ifdef BAS_DIAG
+    { const char *d = getenv("BAS_DEBUG_FLAGS"); A.inject = d ? (atoi(d) & 256) : 0; }
+#endif
+    bool rule_done = false;                                  // the peak rule has been applied inside a kernel tail
+    if (A.direct && want_peak) {
+        if (p.n_wg <= BAS_TAIL_MAX_WG) {                     // the FIR kernel ends in bas_tail: no cleared peak word, no scale launch
+            A.tail_mode = (int)bas_tail_k_last((unsigned)p.n_wg, T.normalize) | (T.normalize << 16);
+            rule_done = T.normalize != 0;
+        } else if (phases & 1) {                             // more workgroups than maxima slots: they max into a cleared word
+            hipError_t e = hipMemsetAsync(peak_dev, 0, sizeof(float), st);
+            if (e != hipSuccess) return bas_fail((int)e, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
+        }
+    }
+    if (!want_peak) peak_bits = nullptr; else peak_bits = reinterpret_cast<unsigned int *>(peak_dev);
     hipEvent_t eb = reinterpret_cast<hipEvent_t>(ev_begin), ee = reinterpret_cast<hipEvent_t>(ev_end);
-    if (p.split) {
-        hipError_t e = bas_fs_launch(A, x, slab, packed, reinterpret_cast<const unsigned *>(plans), y, peak_bits, p.n_wg,
-                                     p.lds_bytes, st, eb, ee);
-        if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int rc = bas_check_launch("bas_render_mix_fused_f32(fs)");
-        if (rc || A.direct) return rc;
-        return bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
-                                      peak_bits, st, "bas_render_mix_fused_f32(reduce)");
+    if (phases & 1) {
+        if (p.split) {
+            hipError_t e = bas_fs_launch(A, x, slab, packed, reinterpret_cast<const unsigned *>(plans), y, peak_bits, p.n_wg,
+                                         p.lds_bytes, st, eb, ee);
+            if (e != hipSuccess) return bas_fail((int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+        } else if (p.quad) {
+            hipError_t e = bas_fq_launch(A, x, slab, packed, reinterpret_cast<const unsigned *>(plans), y, peak_bits, p.n_wg,
+                                         p.lds_bytes, st, eb, ee);
+            if (e != hipSuccess) return bas_fail((int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+        } else {
+            typedef void (*fz_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
+            const fz_fn fn = p.honly ? bas_render_fz_kernel<4, true> : p.nw == 4 ? bas_render_fz_kernel<4, false> : bas_render_fz_kernel<1, false>;
+            hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
+            if (e != hipSuccess) return bas_fail((int)e, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
+            if (eb) (void)hipEventRecord(eb, st);
+            hipLaunchKernelGGL(fn, dim3(p.n_wg), dim3(64 * p.nw), p.lds_bytes, st, A, x, slab, packed,
+                               reinterpret_cast<const unsigned *>(plans), y, peak_bits);
+            if (ee) (void)hipEventRecord(ee, st);
+        }
+        int rc = bas_check_launch(who);
+        if (rc) return rc;
     }
-    if (p.quad) {
-        hipError_t e = bas_fq_launch(A, x, slab, packed, reinterpret_cast<const unsigned *>(plans), y, peak_bits, p.n_wg,
-                                     p.lds_bytes, st, eb, ee);
-        if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        int rc = bas_check_launch("bas_render_mix_fused_f32(fq)");
-        if (rc || A.direct) return rc;
-        return bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
-                                      peak_bits, st, "bas_render_mix_fused_f32(reduce)");
+    if (!(phases & 2)) return 0;
+    if (!A.direct) {                                         // direct output: y and the peak are complete
+        int skipped = 1;
+        int rc = bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
+                                        peak_bits, want_peak ? &T : nullptr, &skipped, st, who);
+        if (rc) return rc;
+        rule_done = !skipped && T.normalize != 0;
     }
-    typedef void (*fz_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
-    const fz_fn fn = p.honly ? bas_render_fz_kernel<4, true> : p.nw == 4 ? bas_render_fz_kernel<4, false> : bas_render_fz_kernel<1, false>;
-    hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
-    if (e != hipSuccess) return bas_fail((int)e, "bas_render_mix_fused_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    if (eb) (void)hipEventRecord(eb, st);
-    hipLaunchKernelGGL(fn, dim3(p.n_wg), dim3(64 * p.nw), p.lds_bytes, st, A, x, slab, packed,
-                       reinterpret_cast<const unsigned *>(plans), y, peak_bits);
-    if (ee) (void)hipEventRecord(ee, st);
-    int rc = bas_check_launch("bas_render_mix_fused_f32(fz)");
-    if (rc || A.direct) return rc;                           // direct output: y and the peak are complete
-    return bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
-                                  peak_bits, st, "bas_render_mix_fused_f32(reduce)");
+    if (normalize && !rule_done) return bas_scale_by_peak_f32(y, 2 * T_out, peak_dev, stream);
+    return 0;
+}
+
+extern "C" int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed, const void *plans,
+                                        int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y,
+                                        int accumulate, float *peak, int normalize, void *ws, size_t ws_bytes,
+                                        bas_stream_t stream) {
+    return fused_impl("bas_render_mix_fused_f32", 3, x, x_stride, packed, plans, n_src, T_in, K, S, L, U, ndir, y, accumulate,
+                      peak, normalize, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int bas_render_mix_fused_profiled_f32(const float *x, long x_stride, const float *packed, const void *plans,
+                                                 int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y,
+                                                 int accumulate, float *peak, int normalize, void *ws, size_t ws_bytes,
+                                                 bas_stream_t stream, void *ev_begin, void *ev_end) {
+    return fused_impl("bas_render_mix_fused_profiled_f32", 3, x, x_stride, packed, plans, n_src, T_in, K, S, L, U, ndir, y,
+                      accumulate, peak, normalize, ws, ws_bytes, stream, ev_begin, ev_end);
+}
+
+extern "C" int bas_render_fused_fir_f32(const float *x, long x_stride, const float *packed, const void *plans, int n_src,
+                                        long T_in, int K, int S, int L, int U, int ndir, float *y, int accumulate,
+                                        float *peak, int normalize, void *ws, size_t ws_bytes, bas_stream_t stream) {
+    return fused_impl("bas_render_fused_fir_f32", 1, x, x_stride, packed, plans, n_src, T_in, K, S, L, U, ndir, y, accumulate,
+                      peak, normalize, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int bas_render_fused_reduce_f32(const float *x, long x_stride, const float *packed, const void *plans, int n_src,
+                                           long T_in, int K, int S, int L, int U, int ndir, float *y, int accumulate,
+                                           float *peak, int normalize, void *ws, size_t ws_bytes, bas_stream_t stream) {
+    return fused_impl("bas_render_fused_reduce_f32", 2, x, x_stride, packed, plans, n_src, T_in, K, S, L, U, ndir, y,
+                      accumulate, peak, normalize, ws, ws_bytes, stream, nullptr, nullptr);
 }

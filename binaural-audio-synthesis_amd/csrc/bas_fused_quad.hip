@@ -19,6 +19,7 @@
 #define FZ_NT_LOADS 1
 #endif
 
+#if FZ_ASM
 __global__ __launch_bounds__(256, 2) void bas_render_fq_kernel(
     FzArgs A, const float *__restrict__ x,                   // [n_src] rows of T_in floats, stride A.x_stride
     float *__restrict__ slab,                                // [n_wg][parts_per_wg][2][tile]
@@ -56,7 +57,11 @@ __global__ __launch_bounds__(256, 2) void bas_render_fq_kernel(
     const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
     const long n_pass = (unit1 - unit0) * nseg;
     if (!A.direct && peak_bits && blockIdx.x == 0 && tid0 == 0) *peak_bits = 0u;   // the reduce kernel maxes into it later
-    if (n_pass <= 0) return;
+    if (n_pass <= 0) {
+        if (A.direct && A.tail_mode) bas_tail<THREADS>(fz_tail(A, y, peak_bits), 0.f);
+        return;
+    }
+    unsigned wmax_bits = 0u;                                 // direct output with a tail: max|y| wave 0 has stored (uniform)
     if (tid0 < NW) flags[tid0] = 0u;                         // hand-over flags of the boundary IRs: no pass has id 0
                                                              // (ordered before their first use by the first pass's barrier)
     f32x32 accA, accB, accP;                                 // half-rate partial sums (bas_fir.h), pinned to v[0:97] by the block
@@ -99,34 +104,13 @@ __global__ __launch_bounds__(256, 2) void bas_render_fq_kernel(
             }
             if (A.direct) {                                  // uniform
                 const long n0 = t * TILE + 32 * lane0;       // this lane's first output
-                float lmax = 0.f;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float *ye = y + (long)e * A.T_out + n0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        f32x4 v = e == 0 ? f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x}
-                                         : f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y};
-                        const long n = n0 + 4 * i;
-                        if (n + 3 < A.T_out) {
-                            f32x4_a4 *p = reinterpret_cast<f32x4_a4 *>(ye + 4 * i);   // (the right ear starts at 4 T_out bytes)
-                            if (A.accumulate) v += *p;
-                            *p = v;
-                            lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-                        } else {
-                            const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (n + j < A.T_out) {
-                                    const float r = A.accumulate ? vv[j] + ye[4 * i + j] : vv[j];
-                                    ye[4 * i + j] = r;
-                                    lmax = fmaxf(lmax, fabsf(r));
-                                }
-                            }
-                        }
-                    }
+                const float lmax = fz_store_row_direct(acc, y, A.T_out, n0, A.accumulate, A.tail_mode != 0);
+                if (A.tail_mode) {
+                    const unsigned b = fz_wave_max_bits(lmax);
+                    wmax_bits = b > wmax_bits ? b : wmax_bits;
+                } else if (peak_bits) {
+                    bas_wave_peak_max(lmax, peak_bits);
                 }
-                if (peak_bits) bas_wave_peak_max(lmax, peak_bits);
             } else {
                 float *dst = slab_wg + (t - first_tile) * 2 * TILE + 32 * lane0;
                 f32x4 *l4 = reinterpret_cast<f32x4 *>(dst);
@@ -266,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void bas_render_fq_kernel(
                 if (i == 0 && wv > 0) {                      // (uniform) the previous wave's last slot needs this IR
                     bnd[wv * 64 + lane] = h;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                    if (lane == 0) flags[wv] = pass_id;
+                    if (lane == 0 && !fz_inject(A)) flags[wv] = pass_id;
                 }
                 if (i > 0) {                                 // slot slot_a + i - 1, written once IR i is known
                     f32x2 h0a, h0b, da, db;
@@ -282,11 +266,10 @@ __global__ __launch_bounds__(256, 2) void bas_render_fq_kernel(
                 pl = pl_next;
             }
             if (need_next) {                                 // (uniform) IR slot_b comes from the next wave's LDS copy
-                int spins = 0;                               // it stored that IR first thing: normally already there
-                while ((unsigned)__builtin_amdgcn_readfirstlane(flags[wv + 1]) != pass_id && ++spins < (1 << 22))
-                    __builtin_amdgcn_s_sleep(1);
+                const bool got = fz_wait_handover(flags + wv + 1, pass_id, A);   // it stored that IR first thing
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const f32x4 nx = bnd[(wv + 1) * 64 + lane];
+                f32x4 nx = bnd[(wv + 1) * 64 + lane];
+                if (!got) nx = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
                 f32x2 h0a, h0b, da, db;
                 fz_pair_ears(prev, h0a, h0b);
                 fz_pair_ears(nx - prev, da, db);
@@ -351,7 +334,10 @@ __global__ __launch_bounds__(256, 2) void bas_render_fq_kernel(
         sg = n_sg;
     }
     flush(open_tile);
+    if (A.direct && A.tail_mode) bas_tail<THREADS>(fz_tail(A, y, peak_bits), __uint_as_float(wmax_bits));
 }
+
+#endif  // FZ_ASM
 
 size_t bas_fq_lds_bytes(int nslots) {
     const int rows = 2048 / 32 + HD_HALO;
@@ -361,10 +347,14 @@ size_t bas_fq_lds_bytes(int nslots) {
 
 hipError_t bas_fq_launch(const FzArgs &A, const float *x, float *slab, const float *packed, const unsigned *plans, float *y,
                          unsigned int *peak_bits, int n_wg, size_t lds_bytes, hipStream_t st, hipEvent_t eb, hipEvent_t ee) {
+#if FZ_ASM
     hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(bas_render_fq_kernel));
     if (e != hipSuccess) return e;
     if (eb) (void)hipEventRecord(eb, st);
     hipLaunchKernelGGL(bas_render_fq_kernel, dim3(n_wg), dim3(256), lds_bytes, st, A, x, slab, packed, plans, y, peak_bits);
     if (ee) (void)hipEventRecord(ee, st);
     return hipSuccess;
+#else
+    return hipErrorNotSupported;                             // (make cppstep: the kernel exists only around the assembly blocks)
+#endif
 }

@@ -37,6 +37,7 @@ __device__ unsigned long long bas_fs_stamps[1024 * 8 * 8];
 #define FS_NOW() 0ull
 #endif
 
+#if FZ_ASM
 // UNITLEN = 128 / 104: every unit is one whole segment of that many taps (L = 121 .. 128; L = 97 .. 104 - the reference's
 // default samples_to_keep is 100, apply_hrtf.py:595) and its five row steps run as ONE assembly block; 0: per-step blocks.
 // (A template parameter, not a branch: with both assembly statements in one loop the compiler keeps the accumulators
@@ -79,7 +80,11 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
     const int nseg = (A.Lp + RT_SEG - 1) / RT_SEG;
     const long n_pass = (unit1 - unit0) * nseg;
     if (!A.direct && peak_bits && blockIdx.x == 0 && tid0 == 0) *peak_bits = 0u;   // the reduce kernel maxes into it later
-    if (n_pass <= 0) return;
+    if (n_pass <= 0) {
+        if (A.direct && A.tail_mode) bas_tail<2 * THREADS>(fz_tail(A, y, peak_bits), 0.f);
+        return;
+    }
+    unsigned wmax_bits = 0u;                                 // direct output with a tail: max|y| this wave has stored (uniform)
     if (tid0 < NW) flags[tid0] = 0u;                         // hand-over flags of the boundary IRs: no pass has id 0
     __syncthreads();
 
@@ -150,34 +155,13 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             accB16 = f32x2{0.f, 0.f};
             if (A.direct) {                                  // uniform
                 const long n0 = t * TILE + 2048 * wv + 32 * lane0;       // this lane's first output
-                float lmax = 0.f;
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    float *ye = y + (long)e * A.T_out + n0;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        f32x4 v = e == 0 ? f32x4{acc[4 * i].x, acc[4 * i + 1].x, acc[4 * i + 2].x, acc[4 * i + 3].x}
-                                         : f32x4{acc[4 * i].y, acc[4 * i + 1].y, acc[4 * i + 2].y, acc[4 * i + 3].y};
-                        const long n = n0 + 4 * i;
-                        if (n + 3 < A.T_out) {
-                            f32x4_a4 *p = reinterpret_cast<f32x4_a4 *>(ye + 4 * i);   // (the right ear starts at 4 T_out bytes)
-                            if (A.accumulate) v += *p;
-                            *p = v;
-                            lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
-                        } else {
-                            const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (n + j < A.T_out) {
-                                    const float r = A.accumulate ? vv[j] + ye[4 * i + j] : vv[j];
-                                    ye[4 * i + j] = r;
-                                    lmax = fmaxf(lmax, fabsf(r));
-                                }
-                            }
-                        }
-                    }
+                const float lmax = fz_store_row_direct(acc, y, A.T_out, n0, A.accumulate, A.tail_mode != 0);
+                if (A.tail_mode) {
+                    const unsigned b = fz_wave_max_bits(lmax);
+                    wmax_bits = b > wmax_bits ? b : wmax_bits;
+                } else if (peak_bits) {
+                    bas_wave_peak_max(lmax, peak_bits);
                 }
-                if (peak_bits) bas_wave_peak_max(lmax, peak_bits);
                 return;
             }
             float *dst = slab_wg + (t - first_tile) * 2 * TILE + 2048 * wv + 32 * lane0;
@@ -413,7 +397,7 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                     if (i == 0 && wv > 0) {                  // (uniform) the previous wave's last slot needs this IR
                         bnd[wv * 64 + lane] = h;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) flags[wv] = pass_id;
+                        if (lane == 0 && !fz_inject(A)) flags[wv] = pass_id;
                     }
                     if (i > 0) {                             // slot slot_a + i - 1, written once IR i is known
                         f32x2 h0a, h0b, da, db;
@@ -429,11 +413,10 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                     pl = pl_next;
                 }
                 if (need_next) {                             // (uniform) IR slot_b comes from the next wave's LDS copy
-                    int spins = 0;                           // it stored that IR first thing: normally already there
-                    while ((unsigned)__builtin_amdgcn_readfirstlane(flags[wv + 1]) != pass_id && ++spins < (1 << 22))
-                        __builtin_amdgcn_s_sleep(1);
+                    const bool got = fz_wait_handover(flags + wv + 1, pass_id, A);   // it stored that IR first thing
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    const f32x4 nx = bnd[(wv + 1) * 64 + lane];
+                    f32x4 nx = bnd[(wv + 1) * 64 + lane];
+                    if (!got) nx = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
                     f32x2 h0a, h0b, da, db;
                     fz_pair_ears(prev, h0a, h0b);
                     fz_pair_ears(nx - prev, da, db);
@@ -456,6 +439,7 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             advance();
         }
     }
+    if (A.direct && A.tail_mode) bas_tail<2 * THREADS>(fz_tail(A, y, peak_bits), __uint_as_float(wmax_bits));
 #ifdef BAS_STAMPS
     if (lane0 == 0 && blockIdx.x < 1024) {
         unsigned long long *d = bas_fs_stamps + (blockIdx.x * 8 + wv8) * 8;
@@ -475,6 +459,8 @@ extern "C" int bas_debug_read_fs_stamps(unsigned long long *host, size_t count) 
 }
 #endif
 
+#endif  // FZ_ASM
+
 int bas_fs_unit_len(int Lp) {                               // segment lengths bas_fir_asm.inc holds a unit block for
     return FS_UNIT_BLOCK && (Lp == 128 || Lp == 104) ? Lp : 0;
 }
@@ -487,6 +473,7 @@ size_t bas_fs_lds_bytes(int nslots) {
 
 hipError_t bas_fs_launch(const FzArgs &A, const float *x, float *slab, const float *packed, const unsigned *plans, float *y,
                          unsigned int *peak_bits, int n_wg, size_t lds_bytes, hipStream_t st, hipEvent_t eb, hipEvent_t ee) {
+#if FZ_ASM
     typedef void (*fs_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
     const fs_fn fn = bas_fs_unit_len(A.Lp) == 128 ? bas_render_fs_kernel<128> : bas_fs_unit_len(A.Lp) == 104 ? bas_render_fs_kernel<104>
                                                                                                               : bas_render_fs_kernel<0>;
@@ -496,4 +483,7 @@ hipError_t bas_fs_launch(const FzArgs &A, const float *x, float *slab, const flo
     hipLaunchKernelGGL(fn, dim3(n_wg), dim3(512), lds_bytes, st, A, x, slab, packed, plans, y, peak_bits);
     if (ee) (void)hipEventRecord(ee, st);
     return hipSuccess;
+#else
+    return hipErrorNotSupported;                             // (make cppstep: the kernel exists only around the assembly blocks)
+#endif
 }

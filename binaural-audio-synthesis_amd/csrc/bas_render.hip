@@ -26,6 +26,7 @@
 #include "bas_internal.h"
 #include "bas_plan.h"
 #include "bas_fir.h"
+#include "bas_tail.h"
 #include <stdlib.h>
 #include <string.h>
 #include <atomic>
@@ -794,11 +795,14 @@ __global__ __launch_bounds__(256) void bas_render_generic_kernel(const float *__
 // ---------------------------------------------------------------------------
 // Slab reduction (fixed order => deterministic) + optional fused max|y|
 // ---------------------------------------------------------------------------
+// T.ctl != null: y is stored with sc1 stores and the kernel ends in bas_tail (bas_tail.h: max|y| without atomics or a cleared
+// peak word, and the peak rule apply_hrtf.py:462-464 without a launch of its own); else the round-3 form (atomicMax into
+// a peak word that the FIR kernel in front has cleared).
 __global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__restrict__ slab, int tile_len,
                                                                 int n_src, int units_per_wg,
                                                                 int parts_per_wg, int n_wg, long T_out,
                                                                 float *__restrict__ y, int accumulate,
-                                                                unsigned int *peak_bits) {
+                                                                unsigned int *peak_bits, BasTail T) {
     float lmax = 0.f;
     const long n4 = (T_out + 3) / 4;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
@@ -817,6 +821,17 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__res
             sl += *reinterpret_cast<const f32x4 *>(p);
             sr += *reinterpret_cast<const f32x4 *>(p + tile_len);
         }
+        if (T.ctl && n + 3 < T_out) {                        // whole quads: one 16-byte sc1 store per ear
+            if (accumulate) {
+                sl += *reinterpret_cast<const f32x4_a4 *>(y + n);
+                sr += *reinterpret_cast<const f32x4_a4 *>(y + T_out + n);
+            }
+            bas_store4_sc1(y + n, sl);
+            bas_store4_sc1(y + T_out + n, sr);
+            lmax = fmaxf(lmax, fmaxf(fmaxf(fmaxf(fabsf(sl.x), fabsf(sl.y)), fmaxf(fabsf(sl.z), fabsf(sl.w))),
+                                     fmaxf(fmaxf(fabsf(sr.x), fabsf(sr.y)), fmaxf(fabsf(sr.z), fabsf(sr.w)))));
+            continue;
+        }
         float vl[4] = {sl.x, sl.y, sl.z, sl.w}, vr[4] = {sr.x, sr.y, sr.z, sr.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -826,13 +841,20 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__res
                     a += y[n + j];
                     b += y[T_out + n + j];
                 }
-                y[n + j] = a;
-                y[T_out + n + j] = b;
+                if (T.ctl) {
+                    bas_store1_sc1(y + n + j, a);
+                    bas_store1_sc1(y + T_out + n + j, b);
+                } else {
+                    y[n + j] = a;
+                    y[T_out + n + j] = b;
+                }
                 lmax = fmaxf(lmax, fmaxf(fabsf(a), fabsf(b)));
             }
         }
     }
-    if (peak_bits) {
+    if (T.ctl) {
+        bas_tail<256>(T, lmax);
+    } else if (peak_bits) {
         bas_block_peak_max(lmax, peak_bits);
     }
 }
@@ -845,7 +867,7 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_wide_kernel(const float *
                                                                      int n_src, int units_per_wg,
                                                                      int parts_per_wg, int n_wg, long T_out,
                                                                      float *__restrict__ y, int accumulate,
-                                                                     unsigned int *peak_bits) {
+                                                                     unsigned int *peak_bits, BasTail T) {
     __shared__ f32x4 part_sum[4][64];
     const int col = threadIdx.x & 3, pl = threadIdx.x >> 2;
     const long cols_per_ear = (T_out + 3) / 4;
@@ -882,12 +904,17 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_wide_kernel(const float *
         for (int j = 0; j < 4; ++j) {
             if (n + j < T_out) {
                 const float a = accumulate ? vv[j] + ye[n + j] : vv[j];
-                ye[n + j] = a;
+                if (T.ctl)
+                    bas_store1_sc1(ye + n + j, a);
+                else
+                    ye[n + j] = a;
                 lmax = fmaxf(lmax, fabsf(a));
             }
         }
     }
-    if (peak_bits) {
+    if (T.ctl) {
+        bas_tail<256>(T, lmax);
+    } else if (peak_bits) {
         bas_block_peak_max(lmax, peak_bits);
     }
 }
@@ -925,6 +952,30 @@ __global__ __launch_bounds__(256) void bas_mix_partials_kernel(const float *__re
     if (peak_bits) {
         bas_block_peak_max(lmax, peak_bits);
     }
+}
+
+// the same sum, max|y| and the peak rule in ONE launch (bas_tail.h): what the root rank of a multi-GPU group runs on the
+// gathered partial mixes (round 3: memset + sum + scale = three launches, ~40 us beside the root's own render)
+__global__ __launch_bounds__(256) void bas_mix_finish_kernel(const float *__restrict__ parts, int n_parts,
+                                                               long part_stride, long n, float *__restrict__ y, BasTail T) {
+    float lmax = 0.f;
+    const long n4 = n >> 2;
+    const bool quads = (part_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(parts) & 15) == 0;   // (uniform)
+    if (quads) {
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < n_parts; ++p) v += *reinterpret_cast<const f32x4 *>(parts + p * part_stride + 4 * i);
+            bas_store4_sc1(y + 4 * i, v);
+            lmax = fmaxf(lmax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        }
+    }
+    for (long i = (quads ? 4 * n4 : 0) + blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+        float v = 0.f;
+        for (int p = 0; p < n_parts; ++p) v += parts[p * part_stride + i];
+        bas_store1_sc1(y + i, v);
+        lmax = fmaxf(lmax, fabsf(v));
+    }
+    bas_tail<256>(T, lmax);
 }
 
 int bas_grid_for(long items, int cap) {
@@ -983,19 +1034,47 @@ hipError_t bas_allow_full_lds(const void *fn) {
     return hipSuccess;
 }
 
-// slabs of partial tiles -> y (fixed order), fused max|y|: shared by the FIR launchers (bas_fused.hip too)
+// how many late workgroups share the rescale of the peak rule (bas_tail.h): they wait for each other, so no more than a
+// fraction of what even a partitioned chip holds at once
+unsigned bas_tail_k_last(unsigned n_wg, int normalize) {
+    if (!normalize) return 1u;
+    unsigned k = (unsigned)bas_device_cus() / 8u;
+    if (k < 1u) k = 1u;
+    if (k > 32u) k = 32u;
+    return n_wg < k ? n_wg : k;
+}
+
+// slabs of partial tiles -> y (fixed order), fused max|y|: shared by the FIR launchers (bas_fused.hip too).
+// tail != null (fused entry points): tail->ctl / wgpeak / y / n / peak / normalize are filled in, the launch geometry here;
+// the kernel then ends in bas_tail.  Launches with more workgroups than the control area has maxima slots keep the round-3
+// form (returns 1 in *tail_skipped: the caller launches the scale kernel itself).
 int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per_wg, int parts_per_wg, int n_wg,
-                           long T_out, float *y, int accumulate, unsigned int *peak_bits, hipStream_t st,
-                           const char *what) {
+                           long T_out, float *y, int accumulate, unsigned int *peak_bits, const BasTail *tail,
+                           int *tail_skipped, hipStream_t st, const char *what) {
     const int parts = (n_src + units_per_wg - 1) / units_per_wg + 1;       // workgroups that can share one tile
+    BasTail T = {};
+    if (tail_skipped) *tail_skipped = 1;
     if (parts > 24) {                                        // many sources on a short signal: sum the parts in parallel
         const long blocks_per_ear = (((T_out + 3) / 4) + 3) / 4;
+        if (tail && 2 * blocks_per_ear <= BAS_TAIL_MAX_WG) {
+            T = *tail;
+            T.n_wg = (unsigned)(2 * blocks_per_ear);
+            T.k_last = bas_tail_k_last(T.n_wg, T.normalize);
+            if (tail_skipped) *tail_skipped = 0;
+        }
         hipLaunchKernelGGL(bas_slab_reduce_wide_kernel, dim3((unsigned)(2 * blocks_per_ear)), dim3(256), 0, st, slab, tile,
-                           n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits);
+                           n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits, T);
         return bas_check_launch(what);
     }
-    hipLaunchKernelGGL(bas_slab_reduce_kernel, dim3(bas_grid_for((T_out + 3) / 4, 2048)), dim3(256), 0, st, slab, tile,
-                       n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits);
+    const int grid = bas_grid_for((T_out + 3) / 4, 2048);
+    if (tail && grid <= BAS_TAIL_MAX_WG) {
+        T = *tail;
+        T.n_wg = (unsigned)grid;
+        T.k_last = bas_tail_k_last(T.n_wg, T.normalize);
+        if (tail_skipped) *tail_skipped = 0;
+    }
+    hipLaunchKernelGGL(bas_slab_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, tile,
+                       n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits, T);
     return bas_check_launch(what);
 }
 
@@ -1095,7 +1174,7 @@ static RenderPlan plan_render(int n_src, long T_in, int K, int S, int L, bool al
 }
 
 extern "C" size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S, int L) {
-    if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return 16;
+    if (n_src <= 0 || T_in <= 0 || K <= 0 || S <= 0 || L <= 0) return BAS_WS_HEAD_BYTES + 16;
     // the kernel is chosen at launch time (pointer alignment, diagnostics override): both fast kernels
     // use the same slab formula, so size for the larger tile count of the two
     RenderPlan p = plan_render(n_src, T_in, K, S, L, true);
@@ -1114,7 +1193,7 @@ extern "C" size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S,
         size_t alt = (size_t)q.n_wg * q.parts_per_wg * 2 * RT_TILE * sizeof(float);
         if (alt > need) need = alt;
     }
-    return need + 16;
+    return BAS_WS_HEAD_BYTES + need + 16;                    // (the head is the library's control area: never slab space)
 }
 
 extern "C" const char *bas_render_kernel_name(int n_src, long T_in, int K, int S, int L) {
@@ -1159,13 +1238,13 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     }
     BAS_REQUIRE(p.units_total < (1L << 31) - 65536, BAS_E_SHAPE,
                 "bas_render_mix_f32: %ld (tile, source) work units exceed 2^31: render in blocks", p.units_total);
-    BAS_REQUIRE(ws && ws_bytes >= p.slab_bytes, BAS_E_WORKSPACE,
-                "bas_render_mix_f32: workspace of %zu bytes needed, %zu given", p.slab_bytes, ws_bytes);
+    BAS_REQUIRE(ws && ws_bytes >= BAS_WS_HEAD_BYTES + p.slab_bytes, BAS_E_WORKSPACE,
+                "bas_render_mix_f32: workspace of %zu bytes needed, %zu given", (size_t)BAS_WS_HEAD_BYTES + p.slab_bytes, ws_bytes);
     RenderArgs A;
     A.x = x; A.x_stride = x_stride; A.H = H; A.n_src = live_src; A.T_in = T_in;
     A.K = K; A.S = S; A.L = L; A.Lp = (L + 7) & ~7; A.n_chunks = n_chunks;
     A.units_total = p.units_total; A.units_per_wg = p.units_per_wg; A.parts_per_wg = p.parts_per_wg;
-    A.slab = reinterpret_cast<float *>(ws);
+    A.slab = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + BAS_WS_HEAD_BYTES);   // (behind the control area)
 #ifdef BAS_DIAG
     { const char *d = getenv("BAS_DEBUG_FLAGS"); A.dbg = d ? atoi(d) : 0; }
 #endif
@@ -1197,7 +1276,7 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     int rc = bas_check_launch(p.kind == KIND_HD ? "bas_render_mix_f32(hd)" : "bas_render_mix_f32(rows32)");
     if (rc) return rc;
     return bas_launch_slab_reduce(A.slab, p.tile, live_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
-                                  peak_bits, st, "bas_render_mix_f32(reduce)");
+                                  peak_bits, nullptr, nullptr, st, "bas_render_mix_f32(reduce)");
 }
 
 extern "C" int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,
@@ -1253,6 +1332,58 @@ extern "C" int bas_mix_partials_f32(const float *parts, int n_parts, long part_s
     hipLaunchKernelGGL(bas_mix_partials_kernel, dim3(bas_grid_for(n, 2048)), dim3(256), 0, st, parts, n_parts,
                        part_stride, n, y, reinterpret_cast<unsigned int *>(peak));
     return bas_check_launch("bas_mix_partials_f32");
+}
+
+extern "C" size_t bas_mix_workspace_bytes(void) { return BAS_WS_HEAD_BYTES; }
+
+extern "C" int bas_mix_finish_f32(const float *parts, int n_parts, long part_stride, long n, float *y, float *peak,
+                                  int normalize, void *ws, size_t ws_bytes, bas_stream_t stream) {
+    BAS_REQUIRE(y || n == 0, BAS_E_NULL, "bas_mix_finish_f32: y is null");
+    BAS_REQUIRE(parts || n_parts == 0 || n == 0, BAS_E_NULL, "bas_mix_finish_f32: parts is null");
+    BAS_REQUIRE(n >= 0 && n_parts >= 0 && part_stride >= n, BAS_E_SHAPE,
+                "bas_mix_finish_f32: need n>=0, n_parts>=0, part_stride>=n");
+    BAS_REQUIRE(ws && ws_bytes >= BAS_WS_HEAD_BYTES, BAS_E_WORKSPACE,
+                "bas_mix_finish_f32: workspace of %zu bytes needed (bas_mix_workspace_bytes), %zu given",
+                (size_t)BAS_WS_HEAD_BYTES, ws_bytes);
+    BAS_REQUIRE(reinterpret_cast<uintptr_t>(ws) % 16 == 0 && reinterpret_cast<uintptr_t>(y) % 16 == 0, BAS_E_ALIGN,
+                "bas_mix_finish_f32: y and ws must be 16-byte aligned");
+    hipStream_t st = bas_stream(stream);
+    if (n == 0) {
+        if (peak) {
+            hipError_t e = hipMemsetAsync(peak, 0, sizeof(float), st);
+            if (e != hipSuccess) return bas_fail((int)e, "bas_mix_finish_f32: hipMemsetAsync: %s", hipGetErrorString(e));
+        }
+        return 0;
+    }
+    BasTail T = {};
+    T.ctl = reinterpret_cast<unsigned *>(ws);
+    T.wgpeak = reinterpret_cast<float *>(reinterpret_cast<char *>(ws) + BAS_CTL_WORDS * 4);
+    T.y = y; T.n = n; T.peak = peak; T.normalize = normalize ? 1 : 0;
+    const int grid = bas_grid_for((n + 3) / 4, 2048);
+    T.n_wg = (unsigned)grid;
+    T.k_last = bas_tail_k_last(T.n_wg, T.normalize);
+    hipLaunchKernelGGL(bas_mix_finish_kernel, dim3(grid), dim3(256), 0, st, parts, n_parts, part_stride, n, y, T);
+    return bas_check_launch("bas_mix_finish_f32");
+}
+
+// Device-side error record of the workspace's control block (bas_tail.h): synchronises the stream, reads four words.
+extern "C" int bas_render_status(void *ws, size_t ws_bytes, bas_stream_t stream) {
+    BAS_REQUIRE(ws && ws_bytes >= BAS_WS_HEAD_BYTES, BAS_E_WORKSPACE, "bas_render_status: not a workspace of this library");
+    hipStream_t st = bas_stream(stream);
+    unsigned rec[4] = {0, 0, 0, 0};
+    unsigned *dev = reinterpret_cast<unsigned *>(ws) + BAS_CTL_STATUS;
+    hipError_t e = hipMemcpyAsync(rec, dev, sizeof(rec), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return bas_fail((int)e, "bas_render_status: %s", hipGetErrorString(e));
+    if (rec[0] != BAS_STATUS_MAGIC0 || rec[1] != BAS_STATUS_MAGIC1) return 0;
+    (void)hipMemsetAsync(reinterpret_cast<unsigned *>(ws), 0, BAS_CTL_WORDS * 4, st);   // whole control block: usable again
+    (void)hipStreamSynchronize(st);
+    return bas_fail((int)hipErrorLaunchTimeOut,
+                    rec[2] == BAS_STATUS_HANDOVER_TIMEOUT
+                        ? "device-side error: a stager wave of workgroup %u never received its neighbour's boundary chunk IR "
+                          "(hand-over timeout); the audio of that launch holds NaN where it happened"
+                        : "device-side error: a late workgroup (%u) of a kernel tail never saw the others arrive; peak rule not applied",
+                    rec[3]);
 }
 
 #ifdef BAS_STAMPS

@@ -12,23 +12,58 @@ one rank's 8*T_out bytes on one link), followed on the root by a fixed-order sum
 import numpy as np
 
 
-def shard_sources(n_src, world_size, rank):
-    """Contiguous, balanced block of source indices owned by `rank`."""
-    base, extra = divmod(n_src, world_size)
-    lo = rank * base + min(rank, extra)
-    return range(lo, lo + base + (1 if rank < extra else 0))
+def shard_sources(n_src, world_size, rank, root_weight=1.0, root=0):
+    """Contiguous block of source indices owned by `rank`.  root_weight = 1: balanced blocks.  root_weight < 1: rank
+    `root` - which also receives the gather and runs the fixed-order sum of the partial mixes while the others are
+    already rendering their next step - takes that fraction of an equal share and the others split the rest evenly
+    (root_weight = 0.75 at 8 ranks of a 256-source scene: 24 sources on the root, 33 or 34 on the others)."""
+    if not (0.0 <= root_weight <= 1.0):
+        raise ValueError("root_weight must lie in [0, 1]")
+    if world_size == 1 or root_weight == 1.0:
+        base, extra = divmod(n_src, world_size)
+        lo = rank * base + min(rank, extra)
+        return range(lo, lo + base + (1 if rank < extra else 0))
+    n_root = int(round(root_weight * n_src / world_size))
+    n_root = max(min(n_root, n_src - (world_size - 1)), 0) if n_src >= world_size else 0
+    base, extra = divmod(n_src - n_root, world_size - 1)
+    sizes = []
+    k = 0
+    for r in range(world_size):
+        if r == root:
+            sizes.append(n_root)
+        else:
+            sizes.append(base + (1 if k < extra else 0))
+            k += 1
+    lo = sum(sizes[:rank])
+    return range(lo, lo + sizes[rank])
 
 
-def _hip_mix_partials(parts):
-    """parts [P, 2, T] device tensor -> (y [2, T], peak [1]) via libbas_hip (fixed order)."""
+_MIX_WS = {}
+
+
+def _mix_workspace(device):
+    """Control area of bas_mix_finish_f32, one per (device, stream)."""
+    import torch
+    from . import _hip
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _MIX_WS.get(key)
+    if ws is None:
+        ws = _MIX_WS[key] = _hip.new_workspace(_hip.lib().bas_mix_workspace_bytes(), device)
+    return ws
+
+
+def _hip_mix_partials(parts, normalize=False):
+    """parts [P, 2, T] device tensor -> (y [2, T], peak [1]) via libbas_hip: fixed-order sum, max|y| and (normalize) the
+    peak rule apply_hrtf.py:462-464 in ONE launch (bas_mix_finish_f32)."""
     import torch
     from . import _hip
     p, _, t = parts.shape
     y = torch.empty((2, t), dtype=torch.float32, device=parts.device)
     peak = torch.empty((1,), dtype=torch.float32, device=parts.device)
     with _hip.on_device(parts.device):
-        _hip.call("bas_mix_partials_f32", _hip.ptr(parts), p, 2 * t, 2 * t, _hip.ptr(y), _hip.ptr(peak),
-                  _hip.current_stream(parts.device))
+        ws = _mix_workspace(parts.device)
+        _hip.call("bas_mix_finish_f32", _hip.ptr(parts), p, 2 * t, 2 * t, _hip.ptr(y), _hip.ptr(peak), int(bool(normalize)),
+                  _hip.ptr(ws), ws.numel(), _hip.current_stream(parts.device))
     return y, peak
 
 
@@ -44,13 +79,17 @@ def gather_mix(partial, group=None, dst=0, mix_fn=None, scale_fn=None, normalize
 
     Returns the final (T_out, 2) mix on rank dst and None elsewhere (with return_peak: the pair
     (mix, peak tensor [1] of the un-normalised mix)).  mix_fn / scale_fn default to the HIP
-    library; CPU tests inject numpy stand-ins to exercise the collective under gloo.
+    library (sum, max|y| and the peak rule in one launch); CPU tests inject numpy stand-ins to
+    exercise the collective under gloo.
     """
     import torch
     import torch.distributed as dist
-    mix_fn = mix_fn or _hip_mix_partials
+    fused_rule = mix_fn is None and scale_fn is None           # the library's mix applies the rule in the same launch
+    mix_fn = mix_fn or (lambda parts: _hip_mix_partials(parts, normalize == "mix"))
     scale_fn = scale_fn or _hip_scale_by_peak
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if not (0 <= dst < world):
+        raise ValueError(f"dst={dst} is not a rank of a group of {world}")
     partial = partial.contiguous()                             # mix_fn and the collective assume dense [2, T]
     if not dist.is_initialized():
         y, peak = mix_fn(partial.unsqueeze(0))
@@ -67,7 +106,7 @@ def gather_mix(partial, group=None, dst=0, mix_fn=None, scale_fn=None, normalize
         else:
             dist.gather(send, gather_list=None, dst=dst, group=group)
             return None
-    if normalize == "mix":
+    if normalize == "mix" and not fused_rule:
         y = scale_fn(y, peak)
     return (y.t(), peak) if return_peak else y.t()
 
@@ -169,20 +208,23 @@ class ShardedStreamRenderer:
     inject stand-ins for both)."""
 
     def __init__(self, tbl, n_src_total, chunksize, subchunksize, group=None, dst=0, stream_factory=None,
-                 mix_fn=None):
+                 mix_fn=None, root_weight=1.0):
         import torch.distributed as dist
         world = dist.get_world_size(group) if dist.is_initialized() else 1
         rank = dist.get_rank(group) if dist.is_initialized() else 0
         if n_src_total < world:
             raise ValueError(f"{n_src_total} sources cannot be sharded over {world} ranks")
-        self.sources = shard_sources(n_src_total, world, rank)
+        self.sources = shard_sources(n_src_total, world, rank, root_weight=root_weight, root=dst)
         if stream_factory is None:
             from .stream import StreamRenderer
             stream_factory = StreamRenderer
         self.local = stream_factory(tbl, len(self.sources), chunksize, subchunksize)
         self.group, self.dst, self.mix_fn = group, dst, mix_fn
         self._peak = None
-        self._solo = not dist.is_initialized() and mix_fn is None     # no process group: the local stream IS the mix
+        # no process group: the local stream IS the mix (its `peak` is then the mix's: a stand-in without that
+        # attribute goes through gather_mix, which measures the peak itself)
+        has_peak = hasattr(type(self.local), "peak") or "peak" in getattr(self.local, "__dict__", {})
+        self._solo = not dist.is_initialized() and mix_fn is None and has_peak
 
     def _combine(self, out_local):
         if self._solo:

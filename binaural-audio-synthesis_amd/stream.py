@@ -98,7 +98,7 @@ class StreamRenderer:
         with _hip.on_device(dev):
             wb = max(lib.bas_render_workspace_bytes(n, t_in, self.K, self.S, self.tbl.L),
                      lib.bas_render_fused_workspace_bytes(n, t_in, self.K, self.S, self.tbl.L))
-        self._ws = torch.empty((wb,), dtype=torch.uint8, device=dev)
+        self._ws = _hip.new_workspace(wb, dev)
         self._ws_plans = torch.empty((lib.bas_interp2d_workspace_bytes(n * (nh + nb)),), dtype=torch.uint8, device=dev)
 
     def input_view(self, B):
@@ -125,7 +125,7 @@ class StreamRenderer:
         # a3, read plans, chunk IRs + FIR + mix (or the stored-IR path for other sizes)
         render_angles_device(x, self.K, self.S, self.tbl, self._elev_all, self._azim_all, normalize="none",
                              out=self._y, ws=self._ws, ws_plans=self._ws_plans, params=(self._idx, self._w),
-                             events=self._events)
+                             events=self._events, want_peak=False)   # (the epilogue tracks the peak of the EMITTED samples)
         # running peak over the emitted samples + carry of the last `halo` inputs and of the angles at their
         # chunk boundaries (t0+B-halo .. t0+B-K) + the angles at t0+B for finish(): one launch
         with _hip.on_device(dev):
@@ -136,6 +136,7 @@ class StreamRenderer:
 
     def _capture(self):
         import torch
+        assert self._events is None, "HIP events of a profiling caller cannot be captured into the block's graph"
         g = torch.cuda.CUDAGraph()
         # thread_local: allocations or copies of OTHER threads (a decoder filling input_view()) do not invalidate
         # the capture; the capture's own allocations come from the graph's private pool
@@ -148,7 +149,9 @@ class StreamRenderer:
         kernels) and, with graph=True, capture the block's hipGraph - all BEFORE streaming starts, so that no
         process() call ever pays for a capture (which synchronises the device for milliseconds).  The carried
         state (input halo, halo angles, end angles, running peak, sample count) is left exactly as it was.
-        Call again after a change of block size or after input_view() had to grow."""
+        Call again after a change of block size or after input_view() had to grow.  The warm-up block is rendered
+        into the renderer's own output buffer: a block view handed out by process() with copy_out=False is overwritten
+        by it - consume such a view before calling prepare() mid-stream."""
         import torch
         assert not self._finished, "stream already finished"
         assert B % self.K == 0 and B > 0, 'block length must be a positive multiple of the chunk size'
@@ -225,7 +228,7 @@ class StreamRenderer:
         elev = torch.cat([e_halo, e_last, e_last], dim=1).contiguous()
         azim = torch.cat([a_halo, a_last, a_last], dim=1).contiguous()
         x = torch.cat([self._xbuf[:, :self.halo], torch.zeros((self.n_src, self.K), dtype=torch.float32, device=dev)], dim=1)
-        y, _ = render_angles_device(x, self.K, self.S, self.tbl, elev, azim, normalize="none")
+        y, _ = render_angles_device(x, self.K, self.S, self.tbl, elev, azim, normalize="none", want_peak=False)
         out = y[:, self.halo:self.halo + L - 1]
         if out.numel():
             self._peak_dev = torch.maximum(self._peak_dev, out.abs().max().reshape(1))

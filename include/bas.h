@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define BAS_ABI_VERSION 4
+#define BAS_ABI_VERSION 5
 
 #define BAS_E_NULL      (-1)   /* a required pointer is NULL                    */
 #define BAS_E_SHAPE     (-2)   /* inconsistent or unsupported sizes             */
@@ -180,9 +180,15 @@ int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, i
  * (8192-output tile, source) units per CU: check bas_render_fused_supported (1 = yes) and
  * otherwise use bas_interp2d_f32 + bas_render_mix_f32.  Scenes with few sources get
  * smaller tiles (2048 outputs) and more workgroups.  ndir = directions in the table (187).
- * ws / ws_bytes: scratch of bas_render_fused_workspace_bytes(...) bytes, 16-byte aligned.
+ * ws / ws_bytes: scratch of bas_render_fused_workspace_bytes(...) bytes, 16-byte aligned.  Its FIRST 64 BYTES are the
+ *    library's control block (a ticket pair of the kernel tails, the device-side error record): zero them ONCE after
+ *    allocating the workspace (hipMemset); every call leaves them zero, so the workspace can be reused call after call and
+ *    inside hipGraph replays.  One workspace serves one stream at a time.
  * x must be 16-byte aligned with x_stride % 4 == 0 (BAS_E_ALIGN otherwise).
- * ev_begin/ev_end: optional hipEvent_t pair recorded around the FIR kernel (may be NULL). 
+ * normalize != 0: the peak rule of make_signal_move_2d (apply_hrtf.py:462-464: m = max|y|; if m > 1: y /= m) is applied
+ *    to y before the call's work on `stream` ends - inside the tail of the last kernel (no launch of its own; the workgroups
+ *    that finish last share the rescale) whenever y is 16-byte aligned, else by bas_scale_by_peak_f32.  `peak` (may be NULL)
+ *    receives max|y| BEFORE the rule either way.
  * n == 0 (no queries / no sources) is served by every entry point: the per-query arrays may then be NULL. */
 int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double *w, int n,
                           int ndir, int L, int U, void *plans, size_t plans_bytes,
@@ -208,9 +214,39 @@ const char *bas_render_fused_kernel_name(int n_src, long T_in, int K, int S, int
 size_t bas_render_fused_workspace_bytes(int n_src, long T_in, int K, int S, int L);
 int bas_render_mix_fused_f32(const float *x, long x_stride, const float *packed,
                              const void *plans, int n_src, long T_in, int K, int S, int L,
-                             int U, int ndir, float *y, int accumulate, float *peak, void *ws,
-                             size_t ws_bytes, bas_stream_t stream, void *ev_begin,
-                             void *ev_end);
+                             int U, int ndir, float *y, int accumulate, float *peak, int normalize,
+                             void *ws, size_t ws_bytes, bas_stream_t stream);
+
+/* Same call; additionally records the caller's hipEvent_t pair (void*, either may be NULL) on `stream` immediately
+ * before and after the FIR kernel (benchmarks time the dominant kernel live with HIP events). */
+int bas_render_mix_fused_profiled_f32(const float *x, long x_stride, const float *packed,
+                                      const void *plans, int n_src, long T_in, int K, int S, int L,
+                                      int U, int ndir, float *y, int accumulate, float *peak,
+                                      int normalize, void *ws, size_t ws_bytes, bas_stream_t stream,
+                                      void *ev_begin, void *ev_end);
+
+/* The two halves of bas_render_mix_fused_f32 as entry points of their own, same arguments: _fir_ launches the FIR kernel
+ * (partial tiles into the workspace - or y itself, complete with peak and rule, for scenes whose tiles are each finished
+ * by one workgroup, e.g. a single source), _reduce_ the fixed-order sum of the partial tiles into y with max|y| and the
+ * peak rule.  Called back to back on one stream they ARE bas_render_mix_fused_f32; apart, a caller can put other work
+ * of its own between them or on a second stream beside either (the read plans of its next block, the carry of its
+ * previous one).  _reduce_ reads only the sizes, y, accumulate, peak, normalize and the workspace. */
+int bas_render_fused_fir_f32(const float *x, long x_stride, const float *packed, const void *plans,
+                             int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y,
+                             int accumulate, float *peak, int normalize, void *ws, size_t ws_bytes,
+                             bas_stream_t stream);
+int bas_render_fused_reduce_f32(const float *x, long x_stride, const float *packed, const void *plans,
+                                int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y,
+                                int accumulate, float *peak, int normalize, void *ws, size_t ws_bytes,
+                                bas_stream_t stream);
+
+/* Device-side error record of a workspace (its control block): synchronises `stream`, returns 0 when no kernel that
+ * used this workspace has reported anything since the last call, else a positive code (hipErrorLaunchTimeOut; text in
+ * bas_last_error) and clears the record.  What can be reported: a stager wave that never received its neighbour's
+ * boundary chunk IR inside a fused kernel (the affected outputs then hold NaN, never plausible audio), a kernel tail
+ * whose late workgroups never saw the others arrive (peak rule not applied).  Neither has ever been observed; both used
+ * to fall through silently.  Costs a stream synchronisation: call it where the caller synchronises anyway. */
+int bas_render_status(void *ws, size_t ws_bytes, bas_stream_t stream);
 
 /* ---- a7 (vii): peak normalisation (apply_hrtf.py:462-464) -------------------
  * m = max|y| over n floats; *peak = m (device float, may be NULL when apply);
@@ -227,6 +263,14 @@ int bas_scale_by_peak_f32(float *y, long n, const float *peak, bas_stream_t stre
  * Used on the root rank after the RCCL gather of the per-GPU partial mixes. */
 int bas_mix_partials_f32(const float *parts, int n_parts, long part_stride, long n, float *y,
                          float *peak, bas_stream_t stream);
+
+/* The same sum, max|y| and - with normalize != 0 - the peak rule (apply_hrtf.py:462-464) in ONE launch: what the root
+ * rank runs on the gathered partial mixes (bas_mix_partials_f32 + bas_scale_by_peak_f32 are a memset and two launches).
+ * y and ws 16-byte aligned; ws: bas_mix_workspace_bytes() bytes whose first 64 are zero when first used (the control
+ * block, as for bas_render_mix_fused_f32; a fused-render workspace may be passed). */
+size_t bas_mix_workspace_bytes(void);
+int bas_mix_finish_f32(const float *parts, int n_parts, long part_stride, long n, float *y, float *peak,
+                       int normalize, void *ws, size_t ws_bytes, bas_stream_t stream);
 
 /* ---- streaming: carried state of block-wise rendering -------
  * No reference counterpart: the reference renders one whole signal held in RAM

@@ -369,14 +369,19 @@ def test_linearity_and_determinism_at_full_size(dev_tables):
     assert ya.shape == (in_length + 127, 2)
 
 
-def test_oracle_spot_checks_at_baseline_size(dev_tables):
-    """BASELINE config 4 on one GPU (256 sources x 10 s, K=512, S=32, L=128): windows of the mix checked
-    directly against the oracle's float64 definition (start, a chunk boundary, a tile boundary of the FIR
-    kernel, the middle of a chunk, the L-1 tail)."""
+@pytest.mark.parametrize("l,kernel", [(128, "bas_render_fs_kernel<128>"), (100, "bas_render_fs_kernel<104>")])
+def test_oracle_spot_checks_at_baseline_size(dev_tables, l, kernel):
+    """BASELINE config 4 on one GPU (256 sources x 10 s, K=512, S=32) at L=128 and at the reference's own default
+    samples_to_keep = 100 (/root/reference/apply_hrtf.py:595), through the SHIPPED library (the kernel it picks is
+    asserted): windows of the mix checked directly against the oracle's float64 definition (start, a chunk boundary,
+    a tile boundary of the FIR kernel, the middle of a chunk, the L-1 tail)."""
     import torch
-    h, d = dev_tables[("consistent", 128)]
-    n_src, n, k, s, l = 256, 441000, 512, 32, 128
+    h, d = dev_tables[("consistent", l)]
+    n_src, n, k, s = 256, 441000, 512, 32
     in_length, out_length = orc.render_lengths(n, k, l)
+    lib = bas._hip.lib()
+    assert os.path.basename(lib._name) == "libbas_hip.so"                # the shipped build, not the diagnostic one
+    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() == kernel
     t = np.arange(0, in_length + 1, k, dtype=np.float64)
     elev = np.empty((n_src, t.size))
     azim = np.empty((n_src, t.size))
@@ -741,6 +746,24 @@ def test_c_caller_of_the_abi(scale):
     r = subprocess.run([exe, scale], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bas_render_hd_kernel" in r.stdout and "rc -2" in r.stdout
+
+
+@pytest.mark.parametrize("scale", ["0.02", "2.0"])
+def test_c_caller_of_the_default_path(scale):
+    """tests/cabi/cabi_check fused: the path the Python layer takes by default, from plain C - bas_table_pack_f32,
+    bas_traj_params_branch_f64, bas_interp2d_plan_f32, bas_render_mix_fused_f32 (peak rule in the kernel tail; scale 2.0
+    makes it fire), bas_render_status - on a scene the plan gives the split-role kernel, checked against
+    oracle/bas_oracle_fir.c fed the chunk IRs of bas_interp2d_f32."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cabi", "cabi_check")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.dirname(exe), "all"])
+    r = subprocess.run([exe, "fused", scale], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bas_render_fs_kernel<128>" in r.stdout and "status 0" in r.stdout
+    peak = float(r.stdout.split("peak before the rule")[1].split(",")[0])
+    assert (peak > 1.0) == (scale == "2.0"), r.stdout
 
 
 def _two_rank_worker(rank, world, port, out_path):

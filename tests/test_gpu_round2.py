@@ -369,12 +369,12 @@ def test_fused_accumulate_and_direct_output(tables, n_src, n, l):
         ns = x_part.shape[0]
         assert lib.bas_render_fused_supported(ns, in_length, k, s, l) == 1
         plans = torch.empty((lib.bas_interp2d_workspace_bytes(idx_part.shape[0]),), dtype=torch.uint8, device="cuda")
-        ws = torch.empty((lib.bas_render_fused_workspace_bytes(ns, in_length, k, s, l),), dtype=torch.uint8, device="cuda")
+        ws = _hip.new_workspace(lib.bas_render_fused_workspace_bytes(ns, in_length, k, s, l), "cuda")
         peak = torch.zeros(1, dtype=torch.float32, device="cuda")
         _hip.call("bas_interp2d_plan_f32", _hip.ptr(d.diffs), _hip.ptr(idx_part), _hip.ptr(w_part), idx_part.shape[0], d.ndir, l,
                   d.upsampling, _hip.ptr(plans), plans.numel(), stream)
         _hip.call("bas_render_mix_fused_f32", _hip.ptr(x_part), x_part.stride(0), _hip.ptr(d.packed), _hip.ptr(plans), ns, in_length,
-                  k, s, l, d.upsampling, d.ndir, _hip.ptr(y), accumulate, _hip.ptr(peak), _hip.ptr(ws), ws.numel(), stream, None, None)
+                  k, s, l, d.upsampling, d.ndir, _hip.ptr(y), accumulate, _hip.ptr(peak), 0, _hip.ptr(ws), ws.numel(), stream)
         return float(peak)
 
     y_one = torch.full((2, t_out), 7.0, dtype=torch.float32, device="cuda")            # must be overwritten

@@ -1,0 +1,244 @@
+"""GPU tests added in round 4: the kernel tails (max|y| and the peak rule apply_hrtf.py:462-464 inside the last kernel of a
+render, bas_tail.h), the one-launch multi-GPU combine (bas_mix_finish_f32), the two halves of the fused render as entry
+points of their own, the device-side error record (bas_render_status) with a fault-injection build, the table builder's
+output through the product loader and interpolate_2d."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import bas_oracle as orc
+import binaural_audio_synthesis_amd as bas
+
+pytestmark = pytest.mark.gpu
+REL = 1e-5
+
+
+def _scene(l, n_src, n, k, gain, seed=0):
+    h = bas.synth.make_table("consistent", 0).truncated(l)
+    sigs = np.stack([bas.synth.integer_noise(seed + 400 + i, n, gain) for i in range(n_src)])
+    in_length = -(-n // k) * k
+    t = np.arange(0, in_length + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        name = ("spiral", "circle_askew", "passing")[i % 3]
+        elev[i], azim[i] = bas.synth.trajectory(name, period_s=0.07 + 0.013 * i, length_s=n / 44100, turns=1.0 + i % 5,
+                                                phase=0.41 * i)(t)
+    return h, sigs, elev, azim, in_length
+
+
+def _device_inputs(h, sigs, elev, azim, in_length):
+    import torch
+    d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    n_src, n = sigs.shape
+    x = torch.zeros((n_src, in_length), dtype=torch.float32, device="cuda")
+    x[:, :n] = torch.from_numpy(sigs).cuda()
+    idx, w = bas.sphere.interpolation_params_device(torch.from_numpy(elev).cuda(), torch.from_numpy(azim).cuda())
+    return d, x, idx.reshape(-1, 4).contiguous(), w.reshape(-1, 3).contiguous()
+
+
+@pytest.mark.parametrize("n_src,n,k,s,l,kernel", [
+    (1, 60000, 512, 32, 128, "bas_render_fq_kernel"),         # one source: the FIR kernel writes y itself and ends in the tail
+    (2, 441000, 512, 32, 128, "bas_render_fq_kernel"),        # slabs + reduce, 216 x 2 units
+    (1, 3300000, 512, 32, 100, "bas_render_fs_kernel<104>"),  # one long source on the split-role kernel: direct output
+    (40, 200000, 512, 32, 128, "bas_render_fs_kernel<128>"),  # slabs + the plain reduce kernel
+    (300, 2048, 512, 32, 128, None),                          # many sources on a short block: the wide reduce kernel
+    (3, 9000, 1024, 64, 100, None),
+])
+@pytest.mark.parametrize("loud", [True, False])
+def test_peak_rule_in_the_kernel_tail(n_src, n, k, s, l, kernel, loud):
+    """normalize = 1 (the rule applied by the late workgroups of the last kernel) against normalize = 0 followed by
+    bas_scale_by_peak_f32 (round 3's separate launch): same bytes, same peak - with the rule firing (peak 2.5) and not
+    firing (0.4); three calls on ONE workspace (the control block resets itself); the peak against torch's own max."""
+    import torch
+    _hip = bas._hip
+    lib = _hip.lib()
+    h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, 1.0 / max(n_src, 1) ** 0.5)
+    d, x, idx, w = _device_inputs(h, sigs, elev, azim, in_length)
+    assert lib.bas_render_fused_supported(n_src, in_length, k, s, l) == 1
+    if kernel is not None:
+        assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() == kernel
+    ws = _hip.new_workspace(lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l), "cuda")
+    probe, _ = bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="none", ws=ws)
+    x *= (2.5 if loud else 0.4) / float(probe.abs().max())    # the render is linear in x
+    plain, pk_plain = bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="none", ws=ws)
+    plain = plain.clone()
+    want_peak = float(plain.abs().max())
+    assert float(pk_plain) == want_peak
+    assert (want_peak > 1.0) == loud, want_peak               # the case is what it claims to be
+    want = plain.clone()
+    _hip.call("bas_scale_by_peak_f32", _hip.ptr(want), want.numel(), _hip.ptr(pk_plain), _hip.current_stream(x.device))
+    for _ in range(3):
+        got, pk = bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="mix", ws=ws)
+        assert float(pk) == want_peak
+        assert torch.equal(got, want)
+    assert not ws[:8].any()                                   # ticket pair back at zero
+    _hip.check_status(ws, x.device)
+    if loud:
+        assert float(got.abs().max()) <= 1.0 + 1e-6
+    # unaligned y: the rule falls back to the scale launch, same result
+    buf = torch.empty((2 * (in_length + l - 1) + 1,), dtype=torch.float32, device="cuda")
+    y_odd = buf[1:].view(2, -1)
+    got2, pk2 = bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="mix", ws=ws, out=y_odd)
+    assert float(pk2) == want_peak and torch.equal(got2, want)
+
+
+def test_tail_under_graph_replay():
+    """The render with the rule in its tail captured into a hipGraph and replayed: the control block must be back at zero
+    after every replay."""
+    import torch
+    _hip = bas._hip
+    n_src, n, k, s, l = 6, 50000, 512, 32, 128
+    h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, 1.5)
+    d, x, idx, w = _device_inputs(h, sigs, elev, azim, in_length)
+    lib = _hip.lib()
+    ws = _hip.new_workspace(lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l), "cuda")
+    wsp = torch.empty((lib.bas_interp2d_workspace_bytes(idx.shape[0]),), dtype=torch.uint8, device="cuda")
+    y = torch.empty((2, in_length + l - 1), dtype=torch.float32, device="cuda")
+    want, pk = bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="mix", ws=ws, ws_plans=wsp)
+    want = want.clone()
+    assert float(pk) > 1.0
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="mix", ws=ws, ws_plans=wsp, out=y)
+    for _ in range(4):
+        y.fill_(9.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, want)
+        assert not ws[:8].any()
+
+
+@pytest.mark.parametrize("n_parts,n,loud", [(8, 2 * 441471, True), (8, 2 * 441471, False), (3, 10007, True), (1, 5, True)])
+def test_mix_finish_equals_sum_then_scale(n_parts, n, loud):
+    """bas_mix_finish_f32 (fixed-order sum + max|y| + peak rule, one launch) against bas_mix_partials_f32 +
+    bas_scale_by_peak_f32, bit for bit; unaligned part strides take the scalar path."""
+    import torch
+    _hip = bas._hip
+    gen = torch.Generator(device="cuda").manual_seed(n_parts + n)
+    stride = n + (3 if n % 4 else 0)
+    parts = (torch.rand((n_parts, stride), generator=gen, device="cuda") - 0.5) * (1.0 if loud else 0.1)
+    st = _hip.current_stream(parts.device)
+    want = torch.empty((n,), dtype=torch.float32, device="cuda")
+    pk0 = torch.empty((1,), dtype=torch.float32, device="cuda")
+    _hip.call("bas_mix_partials_f32", _hip.ptr(parts), n_parts, stride, n, _hip.ptr(want), _hip.ptr(pk0), st)
+    raw = want.clone()
+    _hip.call("bas_scale_by_peak_f32", _hip.ptr(want), n, _hip.ptr(pk0), st)
+    ws = _hip.new_workspace(_hip.lib().bas_mix_workspace_bytes(), "cuda")
+    for normalize, ref in ((1, want), (0, raw), (1, want)):
+        got = torch.full((n,), 5.0, dtype=torch.float32, device="cuda")
+        pk = torch.empty((1,), dtype=torch.float32, device="cuda")
+        _hip.call("bas_mix_finish_f32", _hip.ptr(parts), n_parts, stride, n, _hip.ptr(got), _hip.ptr(pk), normalize,
+                  _hip.ptr(ws), ws.numel(), st)
+        assert float(pk) == float(pk0) and torch.equal(got, ref)
+    assert not ws[:8].any()
+
+
+@pytest.mark.parametrize("n_src,n", [(12, 120000), (1, 60000)])
+def test_fir_and_reduce_as_separate_entry_points(n_src, n):
+    """bas_render_fused_fir_f32 + bas_render_fused_reduce_f32 back to back == bas_render_mix_fused_f32 (bit for bit), with
+    other work of the caller enqueued between the two halves."""
+    import torch
+    _hip = bas._hip
+    lib = _hip.lib()
+    k, s, l = 512, 32, 128
+    h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, 2.0 / n_src)
+    d, x, idx, w = _device_inputs(h, sigs, elev, azim, in_length)
+    t_out = in_length + l - 1
+    ws = _hip.new_workspace(lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l), "cuda")
+    plans = torch.empty((lib.bas_interp2d_workspace_bytes(idx.shape[0]),), dtype=torch.uint8, device="cuda")
+    st = _hip.current_stream(x.device)
+    _hip.call("bas_interp2d_plan_f32", _hip.ptr(d.diffs), _hip.ptr(idx), _hip.ptr(w), idx.shape[0], d.ndir, l, d.upsampling,
+              _hip.ptr(plans), plans.numel(), st)
+
+    def args(y, peak):
+        return (_hip.ptr(x), x.stride(0), _hip.ptr(d.packed), _hip.ptr(plans), n_src, in_length, k, s, l, d.upsampling, d.ndir,
+                _hip.ptr(y), 0, _hip.ptr(peak), 1, _hip.ptr(ws), ws.numel(), st)
+    y1 = torch.empty((2, t_out), dtype=torch.float32, device="cuda")
+    p1 = torch.empty((1,), dtype=torch.float32, device="cuda")
+    _hip.call("bas_render_mix_fused_f32", *args(y1, p1))
+    y2 = torch.full((2, t_out), 3.0, dtype=torch.float32, device="cuda")
+    p2 = torch.empty((1,), dtype=torch.float32, device="cuda")
+    _hip.call("bas_render_fused_fir_f32", *args(y2, p2))
+    other = torch.arange(1000, device="cuda").sum()           # the caller's own work between the halves
+    _hip.call("bas_render_fused_reduce_f32", *args(y2, p2))
+    assert int(other) == 499500
+    assert torch.equal(y1, y2) and float(p1) == float(p2)
+    _hip.check_status(ws, x.device)
+
+
+@pytest.mark.parametrize("n_src,n,nw,split", [(3, 30000, "4", "1"), (3, 30000, "4", "0"), (1, 9000, None, None)])
+def test_handover_timeout_is_reported_not_rendered(monkeypatch, n_src, n, nw, split):
+    """Fault injection (diagnostic build, BAS_DEBUG_FLAGS=256: the stager waves never publish their boundary chunk IR):
+    the neighbours' bounded wait runs out, the affected outputs are NaN instead of plausible audio and
+    bas_render_status returns a positive code with a text - for the split-role, the two-per-CU and the four-wave kernel.
+    The same scene without the injection is clean."""
+    import torch
+    _hip = bas._hip
+    k, s, l = 512, 32, 128
+    h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, 0.1)
+    if nw is not None:
+        monkeypatch.setenv("BAS_FZ_NW", nw)
+        monkeypatch.setenv("BAS_FZ_SPLIT", split)
+    with _hip.use_library(_hip.DIAG_LIB_PATH) as lib:
+        d, x, idx, w = _device_inputs(h, sigs, elev, azim, in_length)
+        ws = _hip.new_workspace(lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l), "cuda")
+        good, _ = bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="none", ws=ws, fused=True)
+        good = good.clone()
+        _hip.check_status(ws, x.device)                       # nothing to report
+        monkeypatch.setenv("BAS_DEBUG_FLAGS", "256")
+        bad, _ = bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="none", ws=ws, fused=True)
+        torch.cuda.synchronize()
+        assert torch.isnan(bad).any() and not torch.isnan(good).any()
+        with pytest.raises(_hip.BasError) as err:
+            _hip.check_status(ws, x.device)
+        assert err.value.code > 0 and "hand-over" in str(err.value)
+        _hip.check_status(ws, x.device)                       # the record is cleared by reading it
+        monkeypatch.delenv("BAS_DEBUG_FLAGS")
+        again, _ = bas.apply_hrtf.render_params_device(x, k, s, d, idx, w, normalize="none", ws=ws, fused=True)
+        assert torch.equal(again, good)                       # the workspace is usable again
+
+
+def test_built_table_through_the_product_loader(tmp_path):
+    """SURVEY 8f-2 (parity unpinned: nothing in the reference can pin upsample_irs.m:15-54 here): a 187-direction table
+    built by upsample_irs.py from synthetic pulse IRs round-trips through the .mat layout of upsample_irs.m:46-53 into
+    load_irs_and_delaydiffs -> interpolate_2d on the device, and agrees with the oracle fed the same file; the delay
+    differences are antisymmetric exactly (upsample_irs.m:31-32) and obey the mesh rule d[i,j] + d[j,k] = d[i,k] that
+    apply_hrtf.py:246-252 relies on to the accuracy of the sub-sample peak estimate."""
+    import scipy.io
+    from binaural_audio_synthesis_amd import upsample_irs as up
+    rng = np.random.default_rng(31)
+    n_dir, n_taps, u, keep = 187, 64, 8, 48
+    pos = 18 + rng.uniform(-5, 5, size=(2, n_dir))
+
+    def pulse(p, width):
+        t = np.arange(n_taps)
+        return np.exp(-0.5 * ((t - p) / width) ** 2) * (1.0 + 0.2 * np.cos(0.9 * (t - p)))
+    hl = np.stack([pulse(p, 2.5) for p in pos[0]])
+    hr = np.stack([pulse(p, 3.0) for p in pos[1]])
+    t = up.upsample_irs(hl, hr, u)
+    path = str(tmp_path / "built.mat")
+    up.save(path, t)
+    rec = scipy.io.loadmat(path)["irs_and_delaydiffs"][0][0]
+    for name in ("diffs_left", "diffs_right"):
+        dd = rec[name]
+        assert np.abs(dd + dd.T).max() <= 1e-12 and not np.diag(dd).any()
+        i, j, kk = rng.integers(0, n_dir, size=(3, 2000))
+        assert np.abs(dd[i, j] + dd[j, kk] - dd[i, kk]).max() <= 1e-3
+    dev_tbl = bas.load_irs_and_delaydiffs(path, samples_to_keep=keep)
+    assert dev_tbl.upsampling == u and dev_tbl.L == keep and dev_tbl.ndir == n_dir
+
+    class HostTable:                                          # what the reference's loader returns (apply_hrtf.py:36-44)
+        upsampling = int(rec["upsampling"][0][0])
+        diffs_left, diffs_right = rec["diffs_left"], rec["diffs_right"]
+        irs_left, irs_right = rec["irs_left"][:, :keep * u], rec["irs_right"][:, :keep * u]
+    worst = 0.0
+    for elev, azim in [(0.0, 0.3), (0.5, 2.0), (-0.7, 5.5), (1.2, 1.0), (1.5707, 0.2), (0.2617993877991494, 3.0), (-2.0, -1.0)]:
+        want = orc.interp2d(HostTable, np.float64(elev), np.float64(azim))
+        got = bas.interpolate_2d(dev_tbl, np.float64(elev), np.float64(azim))
+        worst = max(worst, rel_err(got, want))
+    assert worst <= REL, worst

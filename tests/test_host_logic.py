@@ -157,7 +157,7 @@ def test_small_upsampling_factor_is_refused_by_the_planned_entry_points():
             hip.call("bas_interp2d_plan_f32", a, a, a, 1, 187, 64, u, a, 4000, None)
         assert err.value.code == -2 and "upsampling" in str(err.value)
         with pytest.raises(hip.BasError) as err:
-            hip.call("bas_render_mix_fused_f32", a, 512, a, a, 1, 512, 512, 32, 64, u, 187, a, 0, None, a, 4000, None, None, None)
+            hip.call("bas_render_mix_fused_f32", a, 512, a, a, 1, 512, 512, 32, 64, u, 187, a, 0, None, 0, a, 4000, None)
         assert err.value.code == -2 and "upsampling" in str(err.value)
 
 

@@ -44,7 +44,7 @@ hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_voi
 def mk():
     e = ctypes.c_void_p(); assert hip.hipEventCreate(ctypes.byref(e)) == 0; return e
 y = torch.empty((2, in_length + l - 1), dtype=torch.float32, device="cuda")
-ws = torch.empty((1 << 28,), dtype=torch.uint8, device="cuda")
+ws = bas._hip.new_workspace(1 << 28, "cuda")
 wsp = torch.empty((_hip.lib().bas_interp2d_workspace_bytes(idx.shape[0]),), dtype=torch.uint8, device="cuda")
 handles = [(_hip.use_library(p if os.path.isabs(p) else os.path.join(os.getcwd(), p)), os.path.basename(p)) for p in args.libs]
 res = {name: ([], []) for _, name in handles}

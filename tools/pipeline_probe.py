@@ -23,7 +23,7 @@ for i in range(n_src):
 elev = torch.from_numpy(elev).cuda(); azim = torch.from_numpy(azim).cuda()
 lib = _hip.lib()
 n_q = elev.numel()
-ws = torch.empty((lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l),), dtype=torch.uint8, device="cuda")
+ws = _hip.new_workspace(lib.bas_render_fused_workspace_bytes(n_src, in_length, k, s, l), "cuda")
 y = torch.empty((2, in_length + l - 1), dtype=torch.float32, device="cuda")
 bufs = [dict(idx=torch.empty((n_q, 4), dtype=torch.int32, device="cuda"), w=torch.empty((n_q, 3), dtype=torch.float64, device="cuda"),
              plans=torch.empty((lib.bas_interp2d_workspace_bytes(n_q),), dtype=torch.uint8, device="cuda")) for _ in range(2)]
@@ -38,8 +38,7 @@ def prep(b):
 def fir(b):
     st = _hip.current_stream(x.device)
     _hip.call("bas_render_mix_fused_f32", _hip.ptr(x), x.stride(0), _hip.ptr(tbl.packed), _hip.ptr(b["plans"]), n_src, in_length, k, s, l,
-              tbl.upsampling, tbl.ndir, _hip.ptr(y), 0, _hip.ptr(peak), _hip.ptr(ws), ws.numel(), st, None, None)
-    _hip.call("bas_scale_by_peak_f32", _hip.ptr(y), y.numel(), _hip.ptr(peak), st)
+              tbl.upsampling, tbl.ndir, _hip.ptr(y), 0, _hip.ptr(peak), 1, _hip.ptr(ws), ws.numel(), st)
 
 steps = 300
 for _ in range(100):
