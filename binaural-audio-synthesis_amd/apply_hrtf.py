@@ -419,7 +419,13 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     the reference's numeric branch to reproduce there: "auto" asks the function for its
     value at t = 0 and follows the scalar type it returns (trajectory_branch), so the
     reference's own presets render exactly as the scalar path renders them; a function
-    returning anything but Python floats / np.float64 falls back to the scalar path.
+    returning anything but Python floats / np.float64, or one that raises when called with
+    an array, falls back to the scalar path.  The branch is chosen ONCE, from the value at
+    t = 0: a function whose return type changes with t is rendered in that one branch (the
+    scalar path follows it call by call).  In the "pyfloat" branch the ring weight is the
+    reference's float32 value; its complement (1 - alpha, apply_hrtf.py:90) is formed from
+    the widened value on the device, in float32 in the reference: up to one float32 ulp
+    apart on the `before` weight (parity-unpinned detail, far below the 1e-5 bar).
     """
     import torch
     is_tensor = isinstance(in_signal, torch.Tensor)
@@ -437,14 +443,18 @@ def make_signal_move_2d(in_signal, chunksize: int, subchunksize: int, elev_azim_
     if vectorized:
         if branch not in sphere.BRANCHES:
             raise ValueError("branch must be 'auto', 'f64' or 'pyfloat'")
-        e, a = elev_azim_function(np.arange(0, in_length + 1, chunksize, dtype=np.float64))
-        e, a = np.broadcast_arrays(np.asarray(e, dtype=np.float64), np.asarray(a, dtype=np.float64))
-        if e.shape != (len(times),):
-            e, a = np.broadcast_to(e, (len(times),)), np.broadcast_to(a, (len(times),))
+        try:
+            e, a = elev_azim_function(np.arange(0, in_length + 1, chunksize, dtype=np.float64))
+            e, a = np.broadcast_arrays(np.asarray(e, dtype=np.float64), np.asarray(a, dtype=np.float64))
+            if e.shape != (len(times),):
+                e, a = np.broadcast_to(e, (len(times),)), np.broadcast_to(a, (len(times),))
+        except Exception:                                                    # a function that does not broadcast over an array
+            vectorized = False                                               # (math.*, an `if` on t): the scalar path below
+    if vectorized:
         if not (np.isfinite(e).all() and np.isfinite(a).all()):
             raise ValueError("trajectory contains non-finite angles")
         ea = torch.from_numpy(np.stack([e, a])).to(dev)                      # one H2D copy for both
-    else:
+    if not vectorized:
         idx = np.empty((len(times), 4), dtype=np.int32)
         w = np.empty((len(times), 3), dtype=np.float64)
         for i, t in enumerate(times):

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * NW, 2) void bas_render_fz_kernel(
 #endif
         if (A.direct) {                                      // uniform
             const long n0 = tile * TILE + 2048 * wv + 32 * lane0;       // this lane's first output
-            const float lmax = fz_store_row_direct(acc, y, A.T_out, n0, A.accumulate, A.tail_mode != 0);
+            const float lmax = fz_store_row_direct(acc, y, A.T_out, n0, A.accumulate, false);
             if (A.tail_mode) {
                 const unsigned b = fz_wave_max_bits(lmax);
                 wmax_bits = b > wmax_bits ? b : wmax_bits;
@@ -858,9 +858,12 @@ static int fused_impl(const char *who, int phases, const float *x, long x_stride
 #endif
     bool rule_done = false;                                  // the peak rule has been applied inside a kernel tail
     if (A.direct && want_peak) {
-        if (p.n_wg <= BAS_TAIL_MAX_WG) {                     // the FIR kernel ends in bas_tail: no cleared peak word, no scale launch
-            A.tail_mode = (int)bas_tail_k_last((unsigned)p.n_wg, T.normalize) | (T.normalize << 16);
-            rule_done = T.normalize != 0;
+        // Direct output: the FIR kernel ends in bas_tail for max|y| (no cleared peak word: one launch less), but NOT for the
+        // rule: a lane owns a row here and stores 16 bytes per 128-byte line and instruction, and as sc1 stores - what a
+        // rescale by another workgroup would need - those leave the L2 one by one: the four-wave kernel took 29 us instead
+        // of 14 for one source x 10 s (profiles/r04_ab_kernel_tails.txt).  The rule stays a launch of its own here.
+        if (p.n_wg <= BAS_TAIL_MAX_WG) {
+            A.tail_mode = 1;                                 // k_last = 1, no rule
         } else if (phases & 1) {                             // more workgroups than maxima slots: they max into a cleared word
             hipError_t e = hipMemsetAsync(peak_dev, 0, sizeof(float), st);
             if (e != hipSuccess) return bas_fail((int)e, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));

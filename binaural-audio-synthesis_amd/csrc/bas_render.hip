@@ -1023,7 +1023,11 @@ hipError_t bas_allow_full_lds(const void *fn) {
     for (int i = 0; i < n_seen; ++i)
         if (seen[i].fn == fn) slot = i;
     if (slot >= 0 && (seen[slot].devs & bit)) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // (dynamic + static LDS must fit the CU's 160 KB: the kernel tails of bas_tail.h keep a few words of static LDS)
+    hipFuncAttributes fa;
+    hipError_t e = hipFuncGetAttributes(&fa, fn);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)fa.sharedSizeBytes);
     if (e != hipSuccess) return e;
     if (slot < 0 && n_seen < 64) {
         slot = n_seen++;

@@ -22,7 +22,7 @@
 #define BAS_CTL_STATUS 4        //   4 words: device-side error record (bas_render_status), see BAS_STATUS_MAGIC*
 #define BAS_STATUS_MAGIC0 0xBA5E7707u
 #define BAS_STATUS_MAGIC1 0xDEADFA11u
-#define BAS_TAIL_SPINS (1 << 22)
+#define BAS_TAIL_SPINS (1 << 20)
 
 struct BasTail {
     unsigned *ctl;              // control block (device), zero on entry
@@ -90,13 +90,14 @@ __device__ __forceinline__ void bas_tail(const BasTail &T, float lmax) {
     if (tid == 0) {
         int spins = 0;
         unsigned ok = 1u;
-        while (__hip_atomic_load(T.ctl + BAS_CTL_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T.n_wg) {
+        while (ticket != T.n_wg - 1 &&                       // (the very last one knows)
+               __hip_atomic_load(T.ctl + BAS_CTL_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T.n_wg) {
             if (++spins >= BAS_TAIL_SPINS) {
                 ok = 0u;
                 bas_report_status(T.ctl, BAS_STATUS_TAIL_TIMEOUT, blockIdx.x);
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(16);                    // (~0.5 us: the pollers must not crowd out the arrivals' atomics)
         }
         t_ok = ok;
     }
@@ -126,7 +127,8 @@ __device__ __forceinline__ void bas_tail(const BasTail &T, float lmax) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {                                          // the last one to finish leaves the control block zero
-        const unsigned d = __hip_atomic_fetch_add(T.ctl + BAS_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned d = T.k_last == 1 ? 0u
+                                         : __hip_atomic_fetch_add(T.ctl + BAS_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (d == T.k_last - 1) {
             __hip_atomic_store(T.ctl + BAS_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(T.ctl + BAS_CTL_TICKET, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

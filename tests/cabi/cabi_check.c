@@ -28,8 +28,8 @@ static double lcg(void) {                     /* uniform in [-1, 1) */
 
 /* ---- the default path ------------------------------------------------------------------------------------------- */
 static int check_default_path(double scale) {
-    enum { NDIR = 187, U = 8, L = 128, M = L * U, K = 512, S = 32, N_SRC = 9 };
-    const long n = 300000;                                    /* 37 tiles of 8192 x 9 sources = 333 units > 256 CUs */
+    enum { NDIR = 187, U = 8, L = 128, M = L * U, K = 512, S = 32, N_SRC = 12 };
+    const long n = 300000;                                    /* 37 tiles of 8192 x 12 sources = 444 units > 256 CUs, and too many tiles of 2048 for the four-wave kernel */
     const long T_in = bas_oracle_in_length(n, K), T_out = T_in + L - 1;
     const int n_q = (int)(T_in / K) + 1;
     const long n_query = (long)N_SRC * n_q;
