@@ -279,15 +279,23 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
         // IRs under a tile of 8192 at K = 512; it writes the slots [slot_a, slot_b): slot i holds (IR i, IR i+1 - IR i), so its
         // LAST slot needs the FIRST IR of the next wave, which that wave leaves in LDS as soon as it has it (bnd / flags)
         const int n_ir = A.nslots + 1, base = n_ir / NW, rem = n_ir - base * NW;
-        const int slot_a = wv * base + (wv < rem ? wv : rem);
-        const int slot_b = slot_a + base + (wv < rem ? 1 : 0);
+        const int slot_a = rfl(wv * base + (wv < rem ? wv : rem));     // (wave-uniform, and told so: the buffer loads below
+        const int slot_b = rfl(slot_a + base + (wv < rem ? 1 : 0));    //  take scalar bases - a vector one costs a waterfall loop)
         const int n_ev = slot_a < slot_b ? slot_b - slot_a : 0;
         const bool need_next = n_ev > 0 && slot_b <= A.nslots;      // slot slot_b - 1 exists: it needs IR slot_b
         f32x4 *plw = pl_base + wv * (MAXEV * PL4);
+        // Every vector instruction a stager issues takes a slot from the filter wave of its SIMD (the unit block runs at
+        // 16 800 clocks per unit alone and at 19 900 beside its stager: tools/ubench_unit_block.hip), so nothing that depends
+        // on the lane alone is recomputed per unit (a stager has registers to spare: no opaque thread index here), and the
+        // windows that lie inside the signal - all but a tile's first and last - are fetched by buffer loads whose only
+        // per-lane operand is 16 x lane: bases and strides are scalar.
+        const int tid = tid0 - THREADS;
+        const int lane = tid & 63;
+        const int half = lane >> 5;
+        const int tq = 4 * (lane & 31) + (lane < 32 ? 2 : 0);      // first of the two taps this lane stores
+        const unsigned v16 = 16u * (unsigned)tid, l16 = 16u * (unsigned)lane;
+        const bool all_live = A.L == A.Lp;                   // L a multiple of 8: every tap a lane stores exists
         for (long pid = 0; pid < n_pass; ++pid) {
-            int tid = tid0 - THREADS;
-            asm volatile("" : "+v"(tid));
-            const int lane = tid & 63;
 #ifdef BAS_STAMPS
             const unsigned long long t0 = FS_NOW();
 #endif
@@ -300,17 +308,26 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             f32x4 pv[NPV], xv[NX];
             {
                 const f32x4 *pl_src = reinterpret_cast<const f32x4 *>(plans) + (long)s * (A.n_chunks + 1) * PL4;
+                const int c_first = rfl(G.c0 + slot_a);
+                if (c_first >= 0 && c_first + n_ev - 1 <= A.n_chunks) {      // (uniform) the wave's n_ev x 18 pieces are one run
+                    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<f32x4 *>(pl_src + (long)c_first * PL4), 0, n_ev * PL4 * 16, 0x00020000);
 #pragma unroll
-                for (int r = 0; r < NPV; ++r) {
-                    int p = lane + 64 * r;                   // 16-byte piece of the wave's n_ev * 18
-                    p = p < n_ev * PL4 ? p : 0;
-                    const int i = (p * 3641) >> 16;          // p / 18 for p < 1000
-                    const int c = clampi(G.c0 + slot_a + i, 0, A.n_chunks);
+                    for (int r = 0; r < NPV; ++r)            // (pieces past the run read as zero and are not stored)
+                        pv[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pr, (int)l16, 1024 * r, FZ_NT_LOADS ? 2 : 0));
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NPV; ++r) {
+                        int p = lane + 64 * r;                   // 16-byte piece of the wave's n_ev * 18
+                        p = p < n_ev * PL4 ? p : 0;
+                        const int i = (p * 3641) >> 16;          // p / 18 for p < 1000
+                        const int c = clampi(c_first + i, 0, A.n_chunks);
 #if FZ_NT_LOADS
-                    pv[r] = __builtin_nontemporal_load(pl_src + (long)c * PL4 + (p - i * PL4));
+                        pv[r] = __builtin_nontemporal_load(pl_src + (long)c * PL4 + (p - i * PL4));
 #else
-                    pv[r] = pl_src[(long)c * PL4 + (p - i * PL4)];
+                        pv[r] = pl_src[(long)c * PL4 + (p - i * PL4)];
 #endif
+                    }
                 }
             }
             const long lo_l = -xbase, hi_l = A.T_in - xbase;     // offsets of the signal's first sample / one past its last
@@ -318,19 +335,13 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             const int x_hi = hi_l < -(1 << 30) ? -(1 << 30) : (hi_l > (1 << 30) ? (1 << 30) : (int)hi_l);
             const bool x_inside = x_lo <= 0 && x_hi >= 4 * NX * THREADS;   // whole window inside the signal
             {
-                // (every VALU instruction of a stager takes a slot from the filter wave of its SIMD: a window inside the signal -
-                // all but a tile's first and last - is fetched with ONE per-lane offset and scalar bases, no clamping)
                 const float *xwin = x + (long)s * A.x_stride + xbase;
                 if (x_inside) {
-                    const f32x4 *xq = reinterpret_cast<const f32x4 *>(xwin);
+                    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(xwin), 0,
+                                                                                        16 * NX * THREADS, 0x00020000);
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) {
-#if FZ_NT_LOADS
-                        xv[j] = __builtin_nontemporal_load(xq + j * THREADS + tid);                  // streamed once
-#else
-                        xv[j] = xq[j * THREADS + tid];
-#endif
-                    }
+                    for (int j = 0; j < NX; ++j)             // streamed once
+                        xv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)v16, 16 * THREADS * j, FZ_NT_LOADS ? 2 : 0));
                 } else {
                     asm volatile("" ::: "memory");           // (keeps the two forms apart: merged, every load pays the clamps)
 #pragma unroll
@@ -371,19 +382,18 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
 
             // ---- chunk IRs from the table: lanes 0-31 four adjacent taps of the left ear, lanes 32-63 of the right.
             // Two halves of 8 reads are in flight at any time; slot i - 1 = (IR i-1, IR i - IR i-1) is stored as soon
-            // as IR i is known: both ears of two taps per 16-byte LDS write.
+            // as IR i is known: both ears of two taps per 16-byte LDS write.  The regrouping of the ears is linear, so it is
+            // done once per IR and the difference is formed on the regrouped values.
             {
-                const int half = lane >> 5;
                 const int m = seg0 + 4 * (lane & 31);
                 const int m_c = m < A.L ? m : A.L - 1;       // idle lanes evaluate a valid tap and drop it
                 const unsigned m4 = 4u * (unsigned)m_c;
                 const f32x4 live = f32x4{m < A.L ? 1.f : 0.f, m + 1 < A.L ? 1.f : 0.f, m + 2 < A.L ? 1.f : 0.f,
                                          m + 3 < A.L ? 1.f : 0.f};             // taps >= L read as zero
                 const f32x4 *pl = plw + half * (BAS_PLANS_WORDS / 4);
-                const int tq = 4 * (lane & 31) + (lane < 32 ? 2 : 0);      // first of the two taps this lane stores
                 f32x4 *dst = reinterpret_cast<f32x4 *>(hd) + slot_a * (HD_SLOT / 4) + tq;
                 FzHalf ha, hb;
-                f32x4 prev = f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x2 pa = f32x2{0.f, 0.f}, pb = pa;         // the previous IR, regrouped: (t_a L, t_a R), (t_b L, t_b R)
                 const f32x4 *pl_last = pl + (n_ev > 0 ? n_ev - 1 : 0) * PL4;
                 if (n_ev > 0) fz_issue<0>(tab, pl, m4, L4, ha);
                 // a real loop without branches in its body: the load counters then carry across iterations and each
@@ -393,23 +403,25 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                     fz_issue<1>(tab, pl, m4, L4, hb);
                     f32x4 h = fz_finish<0>(pl, ha, f32x4{0.f, 0.f, 0.f, 0.f});
                     fz_issue<0>(tab, pl_next, m4, L4, ha);
-                    h = fz_finish<1>(pl, hb, h) * live;
+                    h = fz_finish<1>(pl, hb, h);
+                    if (!all_live) h *= live;                // (uniform)
                     if (i == 0 && wv > 0) {                  // (uniform) the previous wave's last slot needs this IR
                         bnd[wv * 64 + lane] = h;
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0 && !fz_inject(A)) flags[wv] = pass_id;
                     }
+                    f32x2 ca, cb;
+                    fz_pair_ears(h, ca, cb);
                     if (i > 0) {                             // slot slot_a + i - 1, written once IR i is known
-                        f32x2 h0a, h0b, da, db;
-                        fz_pair_ears(prev, h0a, h0b);
-                        fz_pair_ears(h - prev, da, db);
+                        const f32x2 da = ca - pa, db = cb - pb;
                         if (tq < Lseg) {
-                            dst[0] = f32x4{h0a.x, h0a.y, da.x, da.y};
-                            dst[1] = f32x4{h0b.x, h0b.y, db.x, db.y};
+                            dst[0] = f32x4{pa.x, pa.y, da.x, da.y};
+                            dst[1] = f32x4{pb.x, pb.y, db.x, db.y};
                         }
                         dst += HD_SLOT / 4;
                     }
-                    prev = h;
+                    pa = ca;
+                    pb = cb;
                     pl = pl_next;
                 }
                 if (need_next) {                             // (uniform) IR slot_b comes from the next wave's LDS copy
@@ -417,12 +429,12 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     f32x4 nx = bnd[(wv + 1) * 64 + lane];
                     if (!got) nx = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
-                    f32x2 h0a, h0b, da, db;
-                    fz_pair_ears(prev, h0a, h0b);
-                    fz_pair_ears(nx - prev, da, db);
+                    f32x2 ca, cb;
+                    fz_pair_ears(nx, ca, cb);
+                    const f32x2 da = ca - pa, db = cb - pb;
                     if (tq < Lseg) {
-                        dst[0] = f32x4{h0a.x, h0a.y, da.x, da.y};
-                        dst[1] = f32x4{h0b.x, h0b.y, db.x, db.y};
+                        dst[0] = f32x4{pa.x, pa.y, da.x, da.y};
+                        dst[1] = f32x4{pb.x, pb.y, db.x, db.y};
                     }
                 }
             }

@@ -209,11 +209,32 @@ def unit_steps(lseg):
     return tuple((max(0, 4 - 4 * r), min(8, (lseg + 32 - 32 * r) >> 3)) for r in range(halo + 1))
 
 
+NOFORM = False
+FMA_KEEP = 8
+SPREAD = 0                      # unit block: LDS reads dealt one by one over the first SPREAD/8 of the FMA run behind them (0: in a burst)
+
+
 def gen_unit(xr_stride, lseg):
     U_STEPS = unit_steps(lseg)
     halo = len(U_STEPS) - 1
     L = []
-    emit = L.append
+
+    def emit(ln):
+        if NOWAIT and ln.startswith("s_waitcnt") and L:
+            return
+        if NOFORM and "%[al" not in ln and (f"{pr(U_AL)}," in ln or ln.startswith("v_pk_add_f32")):
+            return                                              # (sensitivity run: no crossfade forming - wrong results)
+        if FMA_KEEP < 8 and ln.startswith("v_pk_fma_f32") and f"{pr(U_AL)}," not in ln:
+            emit.n = getattr(emit, "n", 0) + 1
+            if emit.n % 8 >= FMA_KEEP:
+                return                                          # (sensitivity run: FMA_KEEP of every 8 FIR FMAs - wrong results)
+        if NOTAPS and ln.startswith("ds_read") and "%[tap" in ln:
+            return
+        if NOX and ln.startswith("ds_read") and "%[xrow]" in ln:
+            return
+        if NOALIGN and ln.startswith(".p2align"):
+            return
+        L.append(ln)
     queue = []                                                  # tags of the LDS reads in flight, oldest first
 
     def align():
@@ -234,14 +255,12 @@ def gen_unit(xr_stride, lseg):
         del queue[:last + 1]
         align()
 
-    def load_x(r):
+    def x_reads(r):
         xb = U_XA if r % 2 == 0 else U_XB
-        for c in range(8):
-            issue(f"x{r}", f"ds_read_b128 {quad(xb + 4 * c)}, %[xrow] offset:{(halo - r) * 16 + c * xr_stride * 16}")
+        return [(f"x{r}", f"ds_read_b128 {quad(xb + 4 * c)}, %[xrow] offset:{(halo - r) * 16 + c * xr_stride * 16}") for c in range(8)]
 
-    def load_taps(r, i, h):
-        for j in range(4):
-            issue(f"t{r}.{i}.{h}", f"ds_read_b128 {quad(U_T[h] + 4 * j)}, %[tap{r}] offset:{(8 * i + 4 * h + j) * 16}")
+    def tap_reads(r, i, h):
+        return [(f"t{r}.{i}.{h}", f"ds_read_b128 {quad(U_T[h] + 4 * j)}, %[tap{r}] offset:{(8 * i + 4 * h + j) * 16}") for j in range(4)]
 
     def form(h):
         tb = U_T[h]
@@ -252,7 +271,9 @@ def gen_unit(xr_stride, lseg):
         for k in range(2):
             emit(f"v_pk_add_f32 {pr(U_GS + 2 * k)}, {pr(U_GE + 2 * k)}, {pr(U_GO + 2 * k)}")
 
-    def fmas(xb, i, h):
+    def fmas(xb, i, h, reads):
+        """the FMAs of half octet (i, h); `reads` (tag, line) go out in front of them (SPREAD = 0) or one by one between them"""
+        lines = []
         for k in range(2):
             jj = 2 * h + k
             dk = 4 * i + jj - 16
@@ -263,18 +284,32 @@ def gen_unit(xr_stride, lseg):
                 xp = pr(xb + 2 * q)
                 xsp, xs_hi = pr(U_XS + 2 * (q >> 1)), q & 1
                 if p >= 0:
-                    emit(f"v_pk_fma_f32 {pr(A0 + 2 * p)}, {pr(U_GE + 2 * k)}, {xp}, {pr(A0 + 2 * p)} op_sel_hi:[1,0,1]")
+                    lines.append(f"v_pk_fma_f32 {pr(A0 + 2 * p)}, {pr(U_GE + 2 * k)}, {xp}, {pr(A0 + 2 * p)} op_sel_hi:[1,0,1]")
                     sel = "op_sel:[0,1,0]" if xs_hi else "op_sel_hi:[1,0,1]"
-                    emit(f"v_pk_fma_f32 {pr(P0 + 2 * p)}, {pr(U_GS + 2 * k)}, {xsp}, {pr(P0 + 2 * p)} {sel}")
+                    lines.append(f"v_pk_fma_f32 {pr(P0 + 2 * p)}, {pr(U_GS + 2 * k)}, {xsp}, {pr(P0 + 2 * p)} {sel}")
                 breg = B16 if p + 1 == 16 else B0 + 2 * (p + 1)
-                emit(f"v_pk_fma_f32 {pr(breg)}, {pr(U_GO + 2 * k)}, {xp}, {pr(breg)} op_sel:[0,1,0]")
+                lines.append(f"v_pk_fma_f32 {pr(breg)}, {pr(U_GO + 2 * k)}, {xp}, {pr(breg)} op_sel:[0,1,0]")
+        reads = list(reads)
+        if not SPREAD or not reads:
+            for t, ln in reads:
+                issue(t, ln)
+            for ln in lines:
+                emit(ln)
+            return
+        span = max(len(lines) * SPREAD // 8, len(reads))       # FMAs the reads are dealt over
+        at = {(k * span) // len(reads): None for k in range(len(reads))}
+        for n_, ln in enumerate(lines):
+            if n_ in at and reads:
+                issue(*reads.pop(0))
+            emit(ln)
+        for t, ln in reads:
+            issue(t, ln)
 
     octets = [(r, i) for r, (lo, hi) in enumerate(U_STEPS) for i in range(lo, hi)]
     emit("s_waitcnt lgkmcnt(0)")                               # (scalar loads of the code around the block return out of order)
     align()
-    load_x(0)
-    load_taps(*octets[0], 0)
-    load_taps(*octets[0], 1)
+    for t, ln in x_reads(0) + tap_reads(*octets[0], 0) + tap_reads(*octets[0], 1):
+        issue(t, ln)
     for n, (r, i) in enumerate(octets):
         xb = U_XA if r % 2 == 0 else U_XB
         nxt = octets[n + 1] if n + 1 < len(octets) else None
@@ -295,11 +330,12 @@ def gen_unit(xr_stride, lseg):
             else:
                 wait_for(f"t{r}.{i}.{h}")
             form(h)
+            reads = []
             if h == 0 and last_of_step and r + 1 < len(U_STEPS):
-                load_x(r + 1)                                   # (in front of the next octet's taps: it is needed first)
+                reads += x_reads(r + 1)                         # (in front of the next octet's taps: it is needed first)
             if nxt:
-                load_taps(*nxt, h)
-            fmas(xb, i, h)
+                reads += tap_reads(*nxt, h)
+            fmas(xb, i, h, reads)
     assert not queue
     return L
 
@@ -331,8 +367,15 @@ def main():
     check = "--check" in sys.argv[1:]                           # compare with the committed file instead of writing it
     # diagnostic variants (wrong results; tools/ubench_lone_wave.hip): --nowait no waits for the LDS reads, --nobranch no octet
     # masks (all live), --notaps no tap reads, --noalign no alignment padding, --nox no x-row reads; --out=FILE
-    global NOWAIT, NOBRANCH, NOTAPS, NOALIGN, NOX, OUT, GENERIC_ONLY, ONE_WAIT
-    ONE_WAIT = "--two-waits" not in sys.argv[1:]                # (A/B: the unit block with a wait in front of every half octet)
+    global NOWAIT, NOBRANCH, NOTAPS, NOALIGN, NOX, OUT, GENERIC_ONLY, ONE_WAIT, SPREAD, NOFORM, FMA_KEEP
+    NOFORM = "--noform" in sys.argv[1:]
+    for a in sys.argv[1:]:
+        if a.startswith("--fma-keep="):
+            FMA_KEEP = int(a[11:])
+    ONE_WAIT = "--two-waits" not in sys.argv[1:]
+    for a in sys.argv[1:]:
+        if a.startswith("--spread="):                           # (A/B: LDS reads of the unit block dealt over the FMAs, in eighths of a run)
+            SPREAD = int(a[9:])                # (A/B: the unit block with a wait in front of every half octet)
     GENERIC_ONLY = "--generic" in sys.argv[1:]                  # (A/B: the round-3 block before the straight-line variants)
     NOWAIT, NOBRANCH, NOTAPS = ("--" + k in sys.argv[1:] for k in ("nowait", "nobranch", "notaps"))
     NOALIGN, NOX = ("--" + k in sys.argv[1:] for k in ("noalign", "nox"))
