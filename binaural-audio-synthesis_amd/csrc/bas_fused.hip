@@ -642,10 +642,14 @@ static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
 
 static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
     FzPlan p = {};
-    if (n_src <= 0 || T_in <= 0 || K < 32 || K % 32 != 0 || S % 32 != 0 || K % S != 0 || L <= 0) return p;
+    // subchunks: multiples of 32 (a row of 32 inputs meets one crossfaded tap set), or 16 - two sets per row, which only the
+    // unit blocks of the split-role kernel hold (scenes with more than one (tile of 8192, source) unit per CU, L = 97 .. 104 or 121 .. 128)
+    const bool s16 = S == 16 && FZ_SPLIT && bas_fs_unit_len((L + 7) & ~7) != 0;
+    if (n_src <= 0 || T_in <= 0 || K < 32 || K % 32 != 0 || (S % 32 != 0 && !s16) || K % S != 0 || L <= 0) return p;
     const long T_out = T_in + L - 1;
     const int cus = bas_device_cus();
     if (fz_slots(4, K) > FZ_MAXSLOTS) {                      // K < 448 or so: h-only rows, four-wave workgroups, two per CU
+        if (s16) return p;
         const long n_tiles = (T_out + 8191) / 8192;
         const int rows_h = fz_slots_exact(4, K, (L + 7) & ~7, n_tiles) + 1;
         const int spw = (rows_h + 3) / 4;
@@ -738,6 +742,7 @@ static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
 #else
         if (units < slots && nw > 1) continue;               // not enough work for this tile: try a smaller one
 #endif
+        if (s16 && !split) return FzPlan{};                  // (subchunks of 16: the split-role kernel or the stored-IR path)
         p.nw = nw;
         p.split = split ? 1 : 0;
         p.quad = quad ? 1 : 0;
@@ -766,6 +771,7 @@ extern "C" const char *bas_render_fused_kernel_name(int n_src, long T_in, int K,
     if (!p.nw) return "";
     if (p.split) {
         const int u = bas_fs_unit_len((L + 7) & ~7);
+        if (S == 16) return u == 128 ? "bas_render_fs_kernel<128,2>" : "bas_render_fs_kernel<104,2>";
         return u == 128 ? "bas_render_fs_kernel<128>" : u == 104 ? "bas_render_fs_kernel<104>" : "bas_render_fs_kernel<0>";
     }
     if (p.quad) return "bas_render_fq_kernel";

@@ -42,7 +42,9 @@ __device__ unsigned long long bas_fs_stamps[1024 * 8 * 8];
 // default samples_to_keep is 100, apply_hrtf.py:595) and its five row steps run as ONE assembly block; 0: per-step blocks.
 // (A template parameter, not a branch: with both assembly statements in one loop the compiler keeps the accumulators
 // elsewhere and copies all 98 into and out of the pinned registers around every block.)
-template <int UNITLEN>
+// NSUB = 2: subchunks of 16 samples (the reference accepts any divisor of the chunk, apply_hrtf.py:401-402): a row of 32
+// inputs meets two crossfaded tap sets; unit blocks only (ffa_unit2_asm).
+template <int UNITLEN, int NSUB = 1>
 __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
     FzArgs A, const float *__restrict__ x,                   // [n_src] rows of T_in floats, stride A.x_stride
     float *__restrict__ slab,                                // [n_wg][parts_per_wg][2][tile]
@@ -217,10 +219,11 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             };
             if constexpr (UNITLEN != 0) {                    // a whole segment of UNITLEN taps: its five row steps in one block
                 unsigned tapv[5];
-                float alv[5];
+                float alv[5], blv[5];
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     alv[r] = weight(m_in);
+                    if constexpr (NSUB == 2) blv[r] = weight(m_in + 16);     // inputs 16-31 of the row: the next subchunk
                     tapv[r] = (unsigned)reinterpret_cast<uintptr_t>(hd + sl * HD_SLOT + (32 * r - 32) * 4);
                     m_in -= 32;
                     if (m_in < 0) {
@@ -228,7 +231,10 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                         sl -= 1;
                     }
                 }
-                ffa_unit_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv);
+                if constexpr (NSUB == 2)
+                    ffa_unit2_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv, blv);
+                else
+                    ffa_unit_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv);
             } else {
 #pragma unroll 1
                 for (int rp = 0; rp <= halo; ++rp) {             // input rows rho' = 0..halo above/at the lane's output row
@@ -487,8 +493,12 @@ hipError_t bas_fs_launch(const FzArgs &A, const float *x, float *slab, const flo
                          unsigned int *peak_bits, int n_wg, size_t lds_bytes, hipStream_t st, hipEvent_t eb, hipEvent_t ee) {
 #if FZ_ASM
     typedef void (*fs_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
-    const fs_fn fn = bas_fs_unit_len(A.Lp) == 128 ? bas_render_fs_kernel<128> : bas_fs_unit_len(A.Lp) == 104 ? bas_render_fs_kernel<104>
-                                                                                                              : bas_render_fs_kernel<0>;
+    const int ul = bas_fs_unit_len(A.Lp);
+    fs_fn fn = ul == 128 ? bas_render_fs_kernel<128> : ul == 104 ? bas_render_fs_kernel<104> : bas_render_fs_kernel<0>;
+    if (A.S == 16) {                                         // (the plan gives subchunks of 16 to this kernel only with a unit block)
+        if (ul == 0) return hipErrorNotSupported;
+        fn = ul == 128 ? bas_render_fs_kernel<128, 2> : bas_render_fs_kernel<104, 2>;
+    }
     hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
     if (e != hipSuccess) return e;
     if (eb) (void)hipEventRecord(eb, st);

@@ -120,7 +120,7 @@ def test_which_fused_kernel_a_shape_gets():
     """bas_render_fused_kernel_name is host logic (the plan of a shape: no launch, no GPU needed - without a device the
     library plans for MI355X's 256 CUs).  BASELINE config 4 and its per-rank shares run the split-role kernel, with the
     unit block for the segment lengths it exists for; scenes of at most two rounds of 2048-output tiles run four waves per
-    tile; chunk sizes below ~448 and K = 448 (20 chunk slots do not fit LDS twice) keep the kernel with two workgroups per CU; S < 32 and tiny chunks are not fused at all."""
+    tile; chunk sizes below ~448 and K = 448 (20 chunk slots do not fit LDS twice) keep the kernel with two workgroups per CU."""
     lib = bas._hip.lib()
     t = 441344
     name = lambda *a: lib.bas_render_fused_kernel_name(*a).decode()
@@ -139,8 +139,13 @@ def test_which_fused_kernel_a_shape_gets():
     assert name(2048, 1024, 512, 32, 128) == "bas_render_fz_kernel<1,0>"       # 2048 short units: eight one-wave workgroups per CU
     assert name(256, t, 448, 32, 128) == "bas_render_fz_kernel<4,0>"
     assert name(256, t, 256, 32, 128) == "bas_render_fz_kernel<4,1>"
-    for shape in ((256, t, 64, 32, 128), (256, t, 512, 16, 128)):
-        assert name(*shape) == "" and lib.bas_render_fused_supported(*shape) == 0
+    # subchunks of 16 (round 4): two crossfaded tap sets per row in the unit blocks of the split-role kernel - big scenes with
+    # L = 97 .. 104 or 121 .. 128; everything else with S < 32, and tiny chunks, are not fused
+    assert name(256, t, 512, 16, 128) == "bas_render_fs_kernel<128,2>" and lib.bas_render_fused_supported(256, t, 512, 16, 128) == 1
+    assert name(32, t, 512, 16, 100) == "bas_render_fs_kernel<104,2>"
+    for shape in ((256, t, 64, 32, 128), (256, t, 512, 8, 128), (256, t, 512, 16, 90), (256, t, 512, 16, 300), (1, t, 512, 16, 128),
+                  (256, t, 256, 16, 128), (256, t, 448, 16, 128)):
+        assert name(*shape) == "" and lib.bas_render_fused_supported(*shape) == 0, shape
 
 
 def test_small_upsampling_factor_is_refused_by_the_planned_entry_points():

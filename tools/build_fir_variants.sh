@@ -14,7 +14,7 @@ while [ $# -ge 2 ]; do
   python3 tools/gen_fir_asm.py $flags --out=$inc > /dev/null
   ( $HIPCC -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DBAS_FIR_ASM_INC="\"$inc\"" -c $C/bas_fused_split.hip -o $C/ab_$name.o &&
     $HIPCC -shared -fPIC --offload-arch=gfx950 $C/bas_abi.o $C/bas_interp.o $C/bas_render.o $C/bas_fused.o $C/ab_$name.o $C/bas_fused_quad.o $C/bas_stream.o -o $C/libab_$name.so ) &
-  $HIPCC -O3 --offload-arch=gfx950 -DFIR_INC="\"$inc\"" tools/ubench_unit_block.hip -o tools/ubench_unit_$name &
+  $HIPCC -O3 -w --offload-arch=gfx950 -DFIR_INC="\"$inc\"" tools/ubench_unit_block.hip -o tools/ubench_unit_$name &
   wait
   echo "built $name ($flags)"
 done

@@ -210,6 +210,7 @@ def unit_steps(lseg):
 
 
 NOFORM = False
+ROLL = 3                        # unit block: rolling x row with this many half-octet tap buffers (0: round 3's two x buffers)
 FMA_KEEP = 8
 SPREAD = 0                      # unit block: LDS reads dealt one by one over the first SPREAD/8 of the FMA run behind them (0: in a burst)
 
@@ -340,6 +341,163 @@ def gen_unit(xr_stride, lseg):
     return L
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# The unit block with a ROLLING x row (round 4): the 8 quads of an x row are not used evenly - octet i of a row step
+# meets inputs q in [12 - 4 i, 31 - 4 i] - so quad c of the NEXT row is read into the same registers as soon as the last
+# octet that needs quad c of this row has gone out (quads 7, 6 behind octet 4, .. quads 1, 0 behind octet 7), three octets
+# before its first use.  One x buffer instead of two: 32 registers free for
+#   * NSUB = 2: subchunks of 16 samples - a row of 32 inputs then meets TWO crossfaded tap sets (inputs 0-15 with the
+#     weight al, 16-31 with al + S / K; apply_hrtf.py:442-443), 12 more formed-tap registers; a half octet forms only the
+#     sets its inputs fall into;
+#   * NBUF = 3 or 4 half-octet tap buffers (reads one and a half or two octets ahead).
+# Same arithmetic and order of accumulation per accumulator as gen_unit (bit-identical output for NSUB = 1).
+R_X, R_XS, R_T0 = 98, 130, 146
+
+
+def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
+    U_STEPS = unit_steps(lseg)
+    halo = len(U_STEPS) - 1
+    r_g = R_T0 + 16 * nbuf                                     # formed taps: nsub x (ge[2], go[2], gs[2]) pairs
+    r_al = r_g + 12 * nsub                                     # the crossfade weights: al (low half), al + S / K (high half)
+    last = r_al + 1
+    L = []
+    emit = L.append
+    queue = []
+
+    def align():
+        emit(".p2align 3")
+
+    def issue(tag, line):
+        emit(line)
+        queue.append(tag)
+
+    landed = set()                                              # tags of the reads a wait has covered
+
+    def wait_for(tags):
+        if not any(t in tags for t in queue):
+            return
+        last_ = max(k for k, t in enumerate(queue) if t in tags)
+        n = len(queue) - 1 - last_
+        assert n <= 15, n
+        emit(f"s_waitcnt lgkmcnt({n})")
+        landed.update(queue[:last_ + 1])
+        del queue[:last_ + 1]
+        align()
+
+    halves = [(r, i, h) for r, (lo, hi) in enumerate(U_STEPS) for i in range(lo, hi) for h in range(2)]
+
+    def fma_list(r, i, h):
+        """(lines, quads read, tap sets used) of half octet (i, h)"""
+        lines, quads, sets = [], set(), set()
+        for k in range(2):
+            jj = 2 * h + k
+            dk = 4 * i + jj - 16
+            for p in range(-1, 16):
+                q = p - dk
+                if not (0 <= q < 16):
+                    continue
+                u = (q >> 3) if nsub == 2 else 0
+                sets.add(u)
+                quads.add(q >> 1)
+                ge, go, gs = r_g + 12 * u, r_g + 12 * u + 4, r_g + 12 * u + 8
+                xp = pr(R_X + 2 * q)
+                xsp, xs_hi = pr(R_XS + 2 * (q >> 1)), q & 1
+                if p >= 0:
+                    lines.append(f"v_pk_fma_f32 {pr(A0 + 2 * p)}, {pr(ge + 2 * k)}, {xp}, {pr(A0 + 2 * p)} op_sel_hi:[1,0,1]")
+                    sel = "op_sel:[0,1,0]" if xs_hi else "op_sel_hi:[1,0,1]"
+                    lines.append(f"v_pk_fma_f32 {pr(P0 + 2 * p)}, {pr(gs + 2 * k)}, {xsp}, {pr(P0 + 2 * p)} {sel}")
+                breg = B16 if p + 1 == 16 else B0 + 2 * (p + 1)
+                lines.append(f"v_pk_fma_f32 {pr(breg)}, {pr(go + 2 * k)}, {xp}, {pr(breg)} op_sel:[0,1,0]")
+        return lines, quads, sets
+
+    plan = [fma_list(*hv) for hv in halves]
+    first_use, last_use = {}, {}
+    for n, ((r, i, h), (_, quads, _)) in enumerate(zip(halves, plan)):
+        for c in quads:
+            first_use.setdefault((r, c), n)
+            last_use[(r, c)] = n
+
+    def x_read(r, c):
+        return (f"x{r}.{c}", f"ds_read_b128 {quad(R_X + 4 * c)}, %[xrow] offset:{(halo - r) * 16 + c * xr_stride * 16}")
+
+    def tap_reads(n):
+        r, i, h = halves[n]
+        b = R_T0 + 16 * (n % nbuf)
+        return [(f"t{n}", f"ds_read_b128 {quad(b + 4 * j)}, %[tap{r}] offset:{(8 * i + 4 * h + j) * 16}") for j in range(4)]
+
+    def form(n, sets):
+        tb = R_T0 + 16 * (n % nbuf)
+        for u in sorted(sets):
+            ge, go, gs = r_g + 12 * u, r_g + 12 * u + 4, r_g + 12 * u + 8
+            wsel = "op_sel_hi:[1,0,1]" if u == 0 else "op_sel:[0,1,0] op_sel_hi:[1,1,1]"   # low / high half of the weight pair
+            for k in range(2):
+                te, to = tb + 4 * (2 * k), tb + 4 * (2 * k + 1)
+                emit(f"v_pk_fma_f32 {pr(ge + 2 * k)}, {pr(te + 2)}, {pr(r_al)}, {pr(te)} {wsel}")
+                emit(f"v_pk_fma_f32 {pr(go + 2 * k)}, {pr(to + 2)}, {pr(r_al)}, {pr(to)} {wsel}")
+            for k in range(2):
+                emit(f"v_pk_add_f32 {pr(gs + 2 * k)}, {pr(ge + 2 * k)}, {pr(go + 2 * k)}")
+
+    # x quads of step r + 1 go out right behind the half octet that uses quad c of step r for the last time
+    x_after = {}                                                # half index n -> reads issued in front of the FMAs of half n
+    for (r, c), n_first in sorted(first_use.items()):
+        if r == 0:
+            continue
+        prev = [last_use[(rr, c)] for rr in range(r) if (rr, c) in last_use]
+        x_after.setdefault((max(prev) + 1) if prev else 0, []).append(x_read(r, c))
+    wait_points = [n for n, (r, i, h) in enumerate(halves) if n == 0 or h == 1] if ONE_WAIT else list(range(len(halves)))
+
+    emit("s_waitcnt lgkmcnt(0)")                               # (scalar loads of the code around the block return out of order)
+    align()
+    for c in sorted(c for (r, c) in first_use if r == 0):
+        issue(*x_read(0, c))
+    for n in range(min(nbuf, len(halves))):
+        for t in tap_reads(n):
+            issue(*t)
+    xs_done = set()
+
+    def needs(m):
+        rm = halves[m][0]
+        return [f"t{m}"] + [f"x{rm}.{c}" for c in sorted(plan[m][1]) if first_use[(rm, c)] == m]
+
+    def sums_of(m):
+        """x_e + x_o of the quads half m is the first to use, once they have landed"""
+        rm = halves[m][0]
+        for c in sorted(plan[m][1]):
+            if first_use[(rm, c)] == m and f"x{rm}.{c}" in landed and (rm, c) not in xs_done:
+                xs_done.add((rm, c))
+                for q in (2 * c, 2 * c + 1):
+                    emit(f"v_add_f32_e64 v{R_XS + q}, v{R_X + 2 * q}, v{R_X + 2 * q + 1}")
+
+    for n, ((r, i, h), (lines, quads, sets)) in enumerate(zip(halves, plan)):
+        nxt = min([m for m in wait_points if m > n], default=len(halves))
+        if n in wait_points:                                    # what the halves up to the next wait point need, as far as it is on its way
+            wait_for([t for m in range(n, nxt) for t in needs(m) if t in queue])
+        missing = [t for t in needs(n) if t not in landed]
+        if missing:                                             # (read too late for the wait point in front: a wait of its own)
+            assert all(t in queue for t in missing), (n, missing)
+            wait_for(missing)
+        for m in range(n, nxt if n in wait_points else n + 1):
+            sums_of(m)
+        assert all(f"x{r}.{c}" in landed and (r, c) in xs_done for c in quads), (n, quads)
+        if (i, h) == (U_STEPS[r][0], 0):                        # first half octet of a step: its weights
+            emit(f"v_mov_b32_e64 v{r_al}, %[al{r}]")
+            if nsub == 2:
+                emit(f"v_mov_b32_e64 v{r_al + 1}, %[bl{r}]")
+        form(n, sets)
+        reads = list(x_after.get(n + 1, []))                    # (quads whose last use is THIS half: behind its FMAs = in front of the next)
+        pre = list(x_after.get(n, [])) if n == 0 else []
+        nx = n + nbuf
+        treads = tap_reads(nx) if nx < len(halves) else []
+        for t in pre + treads:
+            issue(*t)
+        for ln in lines:
+            emit(ln)
+        for t in reads:
+            issue(*t)
+    assert not queue, queue
+    return L, last
+
+
 UNIT_DECL = """
 template <int XR, int LSEG>
 __device__ __forceinline__ void ffa_unit_asm(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
@@ -363,12 +521,37 @@ __device__ __forceinline__ void ffa_unit_asm<{xr}, {lseg}>(f32x32 &accA, f32x32 
 """
 
 
+UNIT2_FUNC = """
+// The same unit for subchunks of 16 samples (apply_hrtf.py:401-402 accepts any divisor of the chunk; :442-443): inputs 0-15 of
+// a row are crossfaded with al[r], inputs 16-31 with bl[r] - two formed tap sets, each formed only by the half octets whose
+// inputs fall into it: {n_fma} v_pk_fma_f32, {n_ds} ds_read_b128, {n_wait} waits.
+template <int XR, int LSEG>
+__device__ __forceinline__ void ffa_unit2_asm(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
+                                               const unsigned (&tap)[5], const float (&al)[5], const float (&bl)[5]);
+template <>
+__device__ __forceinline__ void ffa_unit2_asm<{xr}, {lseg}>(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
+                                               const unsigned (&tap)[5], const float (&al)[5], const float (&bl)[5]) {{
+    asm volatile(
+{body}
+        : "+{{v[0:31]}}"(accA), "+{{v[32:63]}}"(accB), "+{{v[64:95]}}"(accP), "+{{v[96:97]}}"(accB16)
+        : [xrow] "v"(xrow4), [tap0] "v"(tap[0]), [tap1] "v"(tap[1]), [tap2] "v"(tap[2]), [tap3] "v"(tap[3]), [tap4] "v"(tap[4]),
+          [al0] "v"(al[0]), [al1] "v"(al[1]), [al2] "v"(al[2]), [al3] "v"(al[3]), [al4] "v"(al[4]),
+          [bl0] "v"(bl[0]), [bl1] "v"(bl[1]), [bl2] "v"(bl[2]), [bl3] "v"(bl[3]), [bl4] "v"(bl[4])
+        : "memory", {clob});
+}}
+"""
+
+
 def main():
     check = "--check" in sys.argv[1:]                           # compare with the committed file instead of writing it
     # diagnostic variants (wrong results; tools/ubench_lone_wave.hip): --nowait no waits for the LDS reads, --nobranch no octet
     # masks (all live), --notaps no tap reads, --noalign no alignment padding, --nox no x-row reads; --out=FILE
     global NOWAIT, NOBRANCH, NOTAPS, NOALIGN, NOX, OUT, GENERIC_ONLY, ONE_WAIT, SPREAD, NOFORM, FMA_KEEP
+    global ROLL
     NOFORM = "--noform" in sys.argv[1:]
+    for a in sys.argv[1:]:
+        if a.startswith("--roll="):                             # (A/B: the rolling-x unit block with this many tap buffers)
+            ROLL = int(a[7:])
     for a in sys.argv[1:]:
         if a.startswith("--fma-keep="):
             FMA_KEEP = int(a[11:])
@@ -395,12 +578,22 @@ def main():
     if 261 in xrs and not GENERIC_ONLY:
         text += UNIT_DECL
     for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY else ()):
-        ul = gen_unit(261, lseg)
+        if ROLL:
+            ul, u_last = gen_unit_roll(261, lseg, 1, ROLL)
+        else:
+            ul, u_last = gen_unit(261, lseg), U_LAST
         text += UNIT_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
-                                 clob=", ".join(f'"v{r}"' for r in range(U_XA, U_LAST + 1)),
+                                 clob=", ".join(f'"v{r}"' for r in range(U_XA, u_last + 1)),
                                  n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
                                  n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),
                                  n_wait=sum(1 for ln in ul if ln.startswith("s_waitcnt")))
+    for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY and ROLL else ()):     # subchunks of 16: two tap sets per row
+        ul, u_last = gen_unit_roll(261, lseg, 2, ROLL)
+        text += UNIT2_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
+                                  clob=", ".join(f'"v{r}"' for r in range(U_XA, u_last + 1)),
+                                  n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
+                                  n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),
+                                  n_wait=sum(1 for ln in ul if ln.startswith("s_waitcnt")))
     if check:
         same = os.path.exists(OUT) and open(OUT).read() == text
         print(f"{OUT}: {'up to date' if same else 'DIFFERS from what the generator writes'}")
