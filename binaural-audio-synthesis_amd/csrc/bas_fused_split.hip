@@ -42,8 +42,8 @@ __device__ unsigned long long bas_fs_stamps[1024 * 8 * 8];
 // default samples_to_keep is 100, apply_hrtf.py:595) and its five row steps run as ONE assembly block; 0: per-step blocks.
 // (A template parameter, not a branch: with both assembly statements in one loop the compiler keeps the accumulators
 // elsewhere and copies all 98 into and out of the pinned registers around every block.)
-// NSUB = 2: subchunks of 16 samples (the reference accepts any divisor of the chunk, apply_hrtf.py:401-402): a row of 32
-// inputs meets two crossfaded tap sets; unit blocks only (ffa_unit2_asm).
+// NSUB = 2 / 4: subchunks of 16 / 8 samples (the reference accepts any divisor of the chunk, apply_hrtf.py:401-402): a row
+// of 32 inputs meets two / four crossfaded tap sets; unit blocks only (ffa_unit2_asm, ffa_unit4_asm).
 template <int UNITLEN, int NSUB = 1>
 __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
     FzArgs A, const float *__restrict__ x,                   // [n_src] rows of T_in floats, stride A.x_stride
@@ -231,7 +231,10 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                         sl -= 1;
                     }
                 }
-                if constexpr (NSUB == 2)
+                if constexpr (NSUB == 4)                     // (the weights of a row's subchunks: al + u S / K, formed in the block)
+                    ffa_unit4_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv,
+                                               (float)A.S * A.invK);
+                else if constexpr (NSUB == 2)
                     ffa_unit2_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv, blv);
                 else
                     ffa_unit_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv);
@@ -495,9 +498,10 @@ hipError_t bas_fs_launch(const FzArgs &A, const float *x, float *slab, const flo
     typedef void (*fs_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
     const int ul = bas_fs_unit_len(A.Lp);
     fs_fn fn = ul == 128 ? bas_render_fs_kernel<128> : ul == 104 ? bas_render_fs_kernel<104> : bas_render_fs_kernel<0>;
-    if (A.S == 16) {                                         // (the plan gives subchunks of 16 to this kernel only with a unit block)
+    if (A.S == 16 || A.S == 8) {                             // (the plan gives these to this kernel only with a unit block)
         if (ul == 0) return hipErrorNotSupported;
-        fn = ul == 128 ? bas_render_fs_kernel<128, 2> : bas_render_fs_kernel<104, 2>;
+        fn = A.S == 16 ? (ul == 128 ? bas_render_fs_kernel<128, 2> : bas_render_fs_kernel<104, 2>)
+                       : (ul == 128 ? bas_render_fs_kernel<128, 4> : bas_render_fs_kernel<104, 4>);
     }
     hipError_t e = bas_allow_full_lds(reinterpret_cast<const void *>(fn));
     if (e != hipSuccess) return e;

@@ -249,19 +249,20 @@ def _oracle_mix(h, sigs, elev, azim, k, s):
     return orc.render_mix(sigs, k, s, irs, normalize=False)
 
 
+@pytest.mark.parametrize("s", [16, 8])
 @pytest.mark.parametrize("n_src,n,k,l", [
     (3, 30000, 512, 128),          # one unit per workgroup
     (40, 60000, 512, 128),         # two units per workgroup through the two LDS buffers
     (5, 40000, 512, 100),          # the unit block of 104 taps (the reference's default IR length)
-    (2, 50000, 1024, 128),         # longer chunks: 64 subchunks per chunk
+    (2, 50000, 1024, 128),         # longer chunks: 64 / 128 subchunks per chunk
     (4, 30000, 576, 121),          # chunk size not a power of two, L rounded up to 128
     (1, 60000, 512, 128),          # one source: direct output
 ])
-def test_fused_kernel_with_subchunks_of_16_vs_oracle(monkeypatch, n_src, n, k, l):
-    """Subchunks of 16 samples (the reference accepts any divisor of the chunk size, apply_hrtf.py:401-402; :442-443) inside
-    the split-role kernel: a row of 32 inputs meets two crossfaded tap sets (ffa_unit2_asm).  Small scenes through the
-    diagnostic build (which gives the kernel to any scene on request) against the oracle and against the stored-IR path."""
-    s = 16
+def test_fused_kernel_with_subchunks_of_16_and_8_vs_oracle(monkeypatch, n_src, n, k, l, s):
+    """Subchunks of 16 / 8 samples (the reference accepts any divisor of the chunk size, apply_hrtf.py:401-402; :442-443)
+    inside the split-role kernel: a row of 32 inputs meets two / four crossfaded tap sets (ffa_unit2_asm, ffa_unit4_asm).
+    Small scenes through the diagnostic build (which gives the kernel to any scene on request) against the oracle and
+    against the stored-IR path."""
     h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, 0.3 / n_src)
     want = _oracle_mix(h, sigs, elev, azim, k, s)
     monkeypatch.setenv("BAS_FZ_NW", "4")
@@ -270,24 +271,25 @@ def test_fused_kernel_with_subchunks_of_16_vs_oracle(monkeypatch, n_src, n, k, l
         d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
         assert lib.bas_render_fused_supported(n_src, in_length, k, s, l) == 1
         assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() == \
-            f"bas_render_fs_kernel<{128 if l > 104 else 104},2>"
+            f"bas_render_fs_kernel<{128 if l > 104 else 104},{32 // s}>"
         got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=True).cpu().numpy()
         stored = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=False).cpu().numpy()
     assert got.shape == want.shape and rel_err(got, want) <= REL, rel_err(got, want)
     assert rel_err(got, stored) <= 5e-6, rel_err(got, stored)
 
 
-def test_shipped_library_fuses_subchunks_of_16_for_big_scenes():
-    """BASELINE config 4's shape with subchunksize 16: served by the fused path of the SHIPPED library (round 3: stored
+@pytest.mark.parametrize("s", [16, 8])
+def test_shipped_library_fuses_small_subchunks_for_big_scenes(s):
+    """BASELINE config 4's shape with subchunksize 16 / 8: served by the fused path of the SHIPPED library (round 3: stored
     chunk IRs, 0.75 ms per step); a 48-source scene rendered through it against the stored-IR path and oracle windows."""
     import torch
     lib = bas._hip.lib()
     assert os.path.basename(lib._name) == "libbas_hip.so"
-    assert lib.bas_render_fused_supported(256, 441344, 512, 16, 128) == 1
-    assert lib.bas_render_fused_kernel_name(256, 441344, 512, 16, 128).decode() == "bas_render_fs_kernel<128,2>"
-    n_src, n, k, s, l = 48, 140000, 512, 16, 128
+    assert lib.bas_render_fused_supported(256, 441344, 512, s, 128) == 1
+    assert lib.bas_render_fused_kernel_name(256, 441344, 512, s, 128).decode() == f"bas_render_fs_kernel<128,{32 // s}>"
+    n_src, n, k, l = 48, 140000, 512, 128
     h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, 0.5 / n_src)
-    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() == "bas_render_fs_kernel<128,2>"
+    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() == f"bas_render_fs_kernel<128,{32 // s}>"
     d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
     got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none").cpu().numpy()
     stored = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=False).cpu().numpy()

@@ -139,11 +139,12 @@ def test_which_fused_kernel_a_shape_gets():
     assert name(2048, 1024, 512, 32, 128) == "bas_render_fz_kernel<1,0>"       # 2048 short units: eight one-wave workgroups per CU
     assert name(256, t, 448, 32, 128) == "bas_render_fz_kernel<4,0>"
     assert name(256, t, 256, 32, 128) == "bas_render_fz_kernel<4,1>"
-    # subchunks of 16 (round 4): two crossfaded tap sets per row in the unit blocks of the split-role kernel - big scenes with
-    # L = 97 .. 104 or 121 .. 128; everything else with S < 32, and tiny chunks, are not fused
+    # subchunks of 16 / 8 (round 4): two / four crossfaded tap sets per row in the unit blocks of the split-role kernel - big
+    # scenes with L = 97 .. 104 or 121 .. 128; everything else with S < 32, and tiny chunks, are not fused
     assert name(256, t, 512, 16, 128) == "bas_render_fs_kernel<128,2>" and lib.bas_render_fused_supported(256, t, 512, 16, 128) == 1
     assert name(32, t, 512, 16, 100) == "bas_render_fs_kernel<104,2>"
-    for shape in ((256, t, 64, 32, 128), (256, t, 512, 8, 128), (256, t, 512, 16, 90), (256, t, 512, 16, 300), (1, t, 512, 16, 128),
+    assert name(256, t, 512, 8, 128) == "bas_render_fs_kernel<128,4>" and name(64, t, 1024, 8, 100) == "bas_render_fs_kernel<104,4>"
+    for shape in ((256, t, 64, 32, 128), (256, t, 512, 4, 128), (256, t, 512, 16, 90), (256, t, 512, 16, 300), (1, t, 512, 16, 128),
                   (256, t, 256, 16, 128), (256, t, 448, 16, 128)):
         assert name(*shape) == "" and lib.bas_render_fused_supported(*shape) == 0, shape
 

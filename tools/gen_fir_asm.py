@@ -358,8 +358,8 @@ def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
     U_STEPS = unit_steps(lseg)
     halo = len(U_STEPS) - 1
     r_g = R_T0 + 16 * nbuf                                     # formed taps: nsub x (ge[2], go[2], gs[2]) pairs
-    r_al = r_g + 12 * nsub                                     # the crossfade weights: al (low half), al + S / K (high half)
-    last = r_al + 1
+    r_al = r_g + 12 * nsub                                     # the crossfade weights of the row's nsub subchunks, two per pair
+    last = r_al + (3 if nsub == 4 else 1)
     L = []
     emit = L.append
     queue = []
@@ -396,7 +396,7 @@ def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
                 q = p - dk
                 if not (0 <= q < 16):
                     continue
-                u = (q >> 3) if nsub == 2 else 0
+                u = q // (16 // nsub)                          # subchunk of the row that inputs 2 q, 2 q + 1 fall into
                 sets.add(u)
                 quads.add(q >> 1)
                 ge, go, gs = r_g + 12 * u, r_g + 12 * u + 4, r_g + 12 * u + 8
@@ -429,11 +429,12 @@ def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
         tb = R_T0 + 16 * (n % nbuf)
         for u in sorted(sets):
             ge, go, gs = r_g + 12 * u, r_g + 12 * u + 4, r_g + 12 * u + 8
-            wsel = "op_sel_hi:[1,0,1]" if u == 0 else "op_sel:[0,1,0] op_sel_hi:[1,1,1]"   # low / high half of the weight pair
+            wsel = "op_sel_hi:[1,0,1]" if u % 2 == 0 else "op_sel:[0,1,0] op_sel_hi:[1,1,1]"   # low / high half of the weight pair
+            wp = pr(r_al + 2 * (u >> 1))
             for k in range(2):
                 te, to = tb + 4 * (2 * k), tb + 4 * (2 * k + 1)
-                emit(f"v_pk_fma_f32 {pr(ge + 2 * k)}, {pr(te + 2)}, {pr(r_al)}, {pr(te)} {wsel}")
-                emit(f"v_pk_fma_f32 {pr(go + 2 * k)}, {pr(to + 2)}, {pr(r_al)}, {pr(to)} {wsel}")
+                emit(f"v_pk_fma_f32 {pr(ge + 2 * k)}, {pr(te + 2)}, {wp}, {pr(te)} {wsel}")
+                emit(f"v_pk_fma_f32 {pr(go + 2 * k)}, {pr(to + 2)}, {wp}, {pr(to)} {wsel}")
             for k in range(2):
                 emit(f"v_pk_add_f32 {pr(gs + 2 * k)}, {pr(ge + 2 * k)}, {pr(go + 2 * k)}")
 
@@ -483,6 +484,10 @@ def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
             emit(f"v_mov_b32_e64 v{r_al}, %[al{r}]")
             if nsub == 2:
                 emit(f"v_mov_b32_e64 v{r_al + 1}, %[bl{r}]")
+            if nsub == 4:                                       # al + u S / K for the row's subchunks u = 1, 2, 3
+                emit(f"v_add_f32_e64 v{r_al + 1}, v{r_al}, %[dl]")
+                emit(f"v_fma_f32 v{r_al + 2}, 2.0, %[dl], v{r_al}")
+                emit(f"v_add_f32_e64 v{r_al + 3}, v{r_al + 2}, %[dl]")
         form(n, sets)
         reads = list(x_after.get(n + 1, []))                    # (quads whose last use is THIS half: behind its FMAs = in front of the next)
         pre = list(x_after.get(n, [])) if n == 0 else []
@@ -542,6 +547,26 @@ __device__ __forceinline__ void ffa_unit2_asm<{xr}, {lseg}>(f32x32 &accA, f32x32
 """
 
 
+UNIT4_FUNC = """
+// The same unit for subchunks of 8 samples: four formed tap sets per row, each formed only by the half octets whose inputs
+// fall into it; the weights of a row's subchunks are al[r] + u dl, dl = S / K (two tap buffers: the registers go to the
+// formed sets): {n_fma} v_pk_fma_f32, {n_ds} ds_read_b128, {n_wait} waits.
+template <int XR, int LSEG>
+__device__ __forceinline__ void ffa_unit4_asm(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
+                                               const unsigned (&tap)[5], const float (&al)[5], float dl);
+template <>
+__device__ __forceinline__ void ffa_unit4_asm<{xr}, {lseg}>(f32x32 &accA, f32x32 &accB, f32x2 &accB16, f32x32 &accP, unsigned xrow4,
+                                               const unsigned (&tap)[5], const float (&al)[5], float dl) {{
+    asm volatile(
+{body}
+        : "+{{v[0:31]}}"(accA), "+{{v[32:63]}}"(accB), "+{{v[64:95]}}"(accP), "+{{v[96:97]}}"(accB16)
+        : [xrow] "v"(xrow4), [tap0] "v"(tap[0]), [tap1] "v"(tap[1]), [tap2] "v"(tap[2]), [tap3] "v"(tap[3]), [tap4] "v"(tap[4]),
+          [al0] "v"(al[0]), [al1] "v"(al[1]), [al2] "v"(al[2]), [al3] "v"(al[3]), [al4] "v"(al[4]), [dl] "v"(dl)
+        : "memory", {clob});
+}}
+"""
+
+
 def main():
     check = "--check" in sys.argv[1:]                           # compare with the committed file instead of writing it
     # diagnostic variants (wrong results; tools/ubench_lone_wave.hip): --nowait no waits for the LDS reads, --nobranch no octet
@@ -590,6 +615,13 @@ def main():
     for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY and ROLL else ()):     # subchunks of 16: two tap sets per row
         ul, u_last = gen_unit_roll(261, lseg, 2, ROLL)
         text += UNIT2_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
+                                  clob=", ".join(f'"v{r}"' for r in range(U_XA, u_last + 1)),
+                                  n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
+                                  n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),
+                                  n_wait=sum(1 for ln in ul if ln.startswith("s_waitcnt")))
+    for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY and ROLL else ()):     # subchunks of 8: four tap sets per row
+        ul, u_last = gen_unit_roll(261, lseg, 4, 2)
+        text += UNIT4_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
                                   clob=", ".join(f'"v{r}"' for r in range(U_XA, u_last + 1)),
                                   n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
                                   n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),

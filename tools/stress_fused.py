@@ -32,7 +32,13 @@ for case in range(cases):
         k = s * int(rng.integers(-(-256 // s), max(-(-256 // s) + 1, 447 // s + 1)))
     else:
         k = s * int(rng.integers(max(1, -(-448 // s)), max(2, 4096 // s) + 1))
-    big = small_k or rng.random() < (0.7 if force_split else 0.35)                     # enough (tile, source) units for tiles of 8192
+    sub = 0
+    if not small_k and rng.random() < 0.3:                     # subchunks of 16 / 8: the unit blocks with two / four tap sets per row
+        sub = int(rng.choice([16, 8]))
+        s = sub
+        k = 32 * int(rng.integers(14, 65))                     # (the unit blocks exist for K >= 448)
+        l = int(rng.choice([128, 125, 100, 104, 97, 121]))
+    big = small_k or sub or rng.random() < (0.7 if force_split else 0.35)              # enough (tile, source) units for tiles of 8192
     n_src = int(rng.integers(24, 48)) if big else int(rng.integers(1, 9))
     n = int(rng.integers(100000, 160000)) if big else int(rng.integers(1, 40000))
     h = full.truncated(l)
