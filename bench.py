@@ -91,6 +91,9 @@ def parse():
                          "N > 1 code path - async gather to rank 0, fixed-order sum, overlapped steps, device-side "
                          "all_reduce of the settle loop.  Also switched on by BAS_BENCH_FORCE_PG=1")
     ap.add_argument("--no-self-check", action="store_true", help="skip the oracle comparison of the timed path's output")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not measure roofline.traffic (two short child runs under rocprofv3 --pmc, ~10 s each, before "
+                         "anything else; N = 1 scene mode only) - the figure of profiles/fir_hbm_traffic.json is then replayed")
     args = ap.parse_args()
     if os.environ.get("BAS_BENCH_FORCE_PG") == "1":
         args.force_pg = True
@@ -170,6 +173,42 @@ def cpu_baseline(args, n, t_out):
 
 
 # ---------------------------------------------------------------------------
+# HBM traffic of the FIR kernel, measured in THIS invocation: two short child runs of this script under rocprofv3, one per
+# counter (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in separate --pmc passes, kernel trace only beside them).  They
+# run before this process has made any GPU call, like the CPU leg.
+# ---------------------------------------------------------------------------
+def measure_traffic(args):
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="bas_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--settle-ms", "0", "--no-cpu-baseline",
+               "--no-self-check", "--no-traffic", "--sources", str(args.sources), "--seconds", str(args.seconds), "--chunk",
+               str(args.chunk), "--subchunk", str(args.subchunk), "--taps", str(args.taps)] + (["--unfused"] if args.unfused else [])
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, env=env, cwd="/tmp", stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode}): {r.stderr[-200:]}"
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == counter and "bas_" in row["Kernel_Name"]:
+                    per.setdefault(row["Kernel_Name"].split("(")[0].replace("void ", ""), []).append(float(row["Counter_Value"]))
+            out[counter] = {k: sum(v) / len(v) for k, v in per.items()}           # KB per dispatch, by kernel
+        except Exception as e:                                                    # noqa: BLE001
+            return None, f"{counter}: {e}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out, None
+
+
 class HipEvents:
     """Raw hipEvent_t pairs via libamdhip64 (the library records them on the launch stream)."""
 
@@ -671,6 +710,9 @@ def main():
     # The CPU leg starts worker PROCESSES: it runs first, before this process has made any GPU call (anything
     # exec-shaped belongs in front of the first HIP call on this pool), and it does not depend on the GPU run.
     cpu_line = None
+    traffic_pmc, traffic_err = None, None
+    if args.mode == "scene" and world == 1 and not args.no_traffic and not args.force_pg and args.lib is None:
+        traffic_pmc, traffic_err = measure_traffic(args)
     if args.mode == "scene" and world == 1 and not args.no_cpu_baseline:
         n_cpu = int(round(args.seconds * FS))
         cpu_line = cpu_baseline(args, n_cpu, -(-n_cpu // args.chunk) * args.chunk + args.taps - 1)
@@ -742,9 +784,33 @@ def main():
         # the 2-parallel fast FIR row step (3/4 of the multiplications) serves subchunks that are multiples of 32,
         # in the fused kernel and in the stored-IR hd kernel; the other kernels execute the direct form
         fast_fir = s % 32 == 0 and (sc.fused_used or sc.kernel == "bas_render_hd_kernel")
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_parts = None, None, None
+        # what the FIR kernel must move, by part (bytes per launch): x windows (each (tile, source) unit reads its tile + a
+        # 128-sample halo), read plans (288 B per chunk IR, tile's chunks + 2 per unit), the packed table (once per XCD L2 at
+        # least), the slab parts it writes; y and the plans' own write belong to the reduce / plan kernels
+        if sc.fused_used:
+            n_tiles = -(-t_out // 8192)
+            traffic_parts = {"x": 4 * n_src * n_tiles * (8192 + 128), "plans": 288 * n_src * n_tiles * (8192 // k + 2),
+                             "table_x8_xcd": 8 * 4 * (2 * 187 * 8 * (l + 4)), "slabs_written": None, "y": 0}
+        if traffic_pmc is not None:
+            fk = [kn for kn in traffic_pmc["FETCH_SIZE"] if "bas_render_f" in kn or "bas_render_hd" in kn]
+            if fk:
+                f_kb = traffic_pmc["FETCH_SIZE"][fk[0]]
+                w_kb = traffic_pmc["WRITE_SIZE"].get(fk[0], 0.0)
+                # gfx950: FETCH_SIZE counts half of the bytes of wide coalesced streaming reads (the x windows, the plans);
+                # the table gathers are L2 hits.  x and plans are what is doubled; the rest of FETCH_SIZE is taken as it is.
+                traffic = int(2 * f_kb * 1024 + w_kb * 1024)
+                if traffic_parts is not None:
+                    traffic_parts["slabs_written"] = int(w_kb * 1024)
+                traffic_source = (f"measured in this invocation: rocprofv3 --pmc FETCH_SIZE ({f_kb / 1024:.1f} MB) and --pmc "
+                                  f"WRITE_SIZE ({w_kb / 1024:.1f} MB) of {fk[0]} in two child runs of 3 steps; gfx950 correction "
+                                  "(MI355X_MICROARCH.md: FETCH_SIZE x 2 for wide streaming reads) applied to all of FETCH_SIZE: an "
+                                  "upper bound")
+                info["traffic_by_kernel_KB"] = {c: {kn: round(v, 1) for kn, v in d.items()} for c, d in traffic_pmc.items()}
+        elif traffic_err:
+            info["traffic_error"] = traffic_err
         tpath = os.path.join(ROOT, "profiles", "fir_hbm_traffic.json")
-        if os.path.exists(tpath):
+        if traffic is None and os.path.exists(tpath):
             with open(tpath) as f:
                 rec = json.load(f)
             if rec.get("workload") == f"{n_src}x{n}@K{k}S{s}L{l}" and rec.get("fused", False) == sc.fused_used:
@@ -779,7 +845,7 @@ def main():
             "roofline": {"bound": "hbm", "bound_actual": "fp32 VALU at a power-limited clock (see valu; the HBM "
                          "fraction of a perfect 128-tap direct FIR tops out near 15 %)", "achieved": algo_bytes / fir_s / 1e9, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": algo_bytes / fir_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": traffic_source,
+                         "traffic_source": traffic_source, "traffic_parts": traffic_parts,
                          "kernel": sc.kernel + (" (chunk IRs evaluated while staging)" if sc.fused_used else ""),
                          "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes},
             "valu": {"achieved": algo_flops / fir_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",

@@ -179,13 +179,13 @@ def on_device_of(argname_or_index):
     return deco
 
 
-WS_CONTROL_BYTES = 64
+WS_CONTROL_BYTES = 2048                                   # BAS_WS_CONTROL_BYTES of include/bas.h
 
 
 def new_workspace(nbytes, device):
-    """Scratch for the render / mix entry points (include/bas.h): uninitialised device bytes whose first 64 - the
-    library's control block (tail counters, device-side error record) - are zeroed once, here; every call leaves them
-    zero.  One workspace serves one stream at a time."""
+    """Scratch for the render / mix entry points (include/bas.h): uninitialised device bytes whose first 2048 - the
+    library's control block (arrival counters of the kernel tails, device-side error record) - are zeroed once, here; every
+    call leaves the counters zero.  One workspace serves one stream at a time."""
     import torch
     ws = torch.empty((max(int(nbytes), WS_CONTROL_BYTES),), dtype=torch.uint8, device=device)
     ws[:WS_CONTROL_BYTES].zero_()

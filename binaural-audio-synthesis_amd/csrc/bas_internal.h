@@ -25,10 +25,11 @@ struct BasTail;                                        // bas_tail.h
 int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per_wg, int parts_per_wg, int n_wg,
                            long T_out, float *y, int accumulate, unsigned int *peak_bits, const BasTail *tail,
                            int *tail_skipped, hipStream_t st, const char *what);
-// Workspaces of the fused entry points start with a head the library owns: the 64-byte control block (zero between calls)
-// and BAS_TAIL_MAX_WG per-workgroup maxima (bas_tail.h); the slabs follow.
+// Workspaces start with a head the library owns: the 2048-byte control block (zero between calls) and BAS_TAIL_MAX_WG
+// per-workgroup maxima (bas_tail.h); the slabs follow.
 #define BAS_TAIL_MAX_WG 4096
-#define BAS_WS_HEAD_BYTES (64 + 4 * BAS_TAIL_MAX_WG)
+#define BAS_WS_CONTROL_BYTES 2048
+#define BAS_WS_HEAD_BYTES (BAS_WS_CONTROL_BYTES + 4 * BAS_TAIL_MAX_WG)
 
 #define BAS_REQUIRE(cond, code, ...) \
     do { if (!(cond)) return bas_fail((code), __VA_ARGS__); } while (0)

@@ -37,6 +37,8 @@ extern "C" {
 #define BAS_E_ALIGN     (-3)   /* pointer/stride alignment requirement violated */
 #define BAS_E_WORKSPACE (-4)   /* workspace too small                           */
 
+#define BAS_WS_CONTROL_BYTES 2048   /* head of every workspace: the library's control block (see bas_render_mix_fused_f32) */
+
 typedef void *bas_stream_t;    /* hipStream_t */
 
 /* Library / ABI version (BAS_ABI_VERSION). */
@@ -143,7 +145,8 @@ int bas_interp2d_f32(const float *packed, const double *diffs, const int32_t *id
  *   y  [2][T_in + L - 1] f32; overwritten, or added to when accumulate != 0
  *   peak (may be NULL): device float receiving max|y| of the result (:462),
  *      fused into the final pass
- *   ws / ws_bytes: scratch of at least bas_render_workspace_bytes(...) bytes. */
+ *   ws / ws_bytes: scratch of at least bas_render_workspace_bytes(...) bytes; its first BAS_WS_CONTROL_BYTES are the library's
+ *      control block (see bas_render_mix_fused_f32: zero them once after allocating), which this entry point leaves alone. */
 size_t bas_render_workspace_bytes(int n_src, long T_in, int K, int S, int L);
 
 /* Name of the FIR kernel bas_render_mix_f32 launches for these sizes with aligned
@@ -176,14 +179,16 @@ int bas_render_mix_profiled_f32(const float *x, long x_stride, const float *H, i
  * the workgroups evaluate the chunk IRs they need while staging (plans staged in LDS,
  * table samples by buffer loads), so the [n][2][L] IR array never exists in HBM.
  * Served for chunk sizes K >= 448 or so (K % 32 == 0) with subchunks that are multiples
- * of 32, and for K >= 256 when the scene has at least two workgroups' worth of
- * (8192-output tile, source) units per CU: check bas_render_fused_supported (1 = yes) and
+ * of 32, for K >= 256 when the scene has at least two workgroups' worth of
+ * (8192-output tile, source) units per CU, and for subchunks of 16 and 8 samples (the reference accepts any
+ * divisor of the chunk, apply_hrtf.py:401-402) in scenes with more than one such unit per CU and
+ * L = 97 .. 104 or 121 .. 128: check bas_render_fused_supported (1 = yes) and
  * otherwise use bas_interp2d_f32 + bas_render_mix_f32.  Scenes with few sources get
  * smaller tiles (2048 outputs) and more workgroups.  ndir = directions in the table (187).
- * ws / ws_bytes: scratch of bas_render_fused_workspace_bytes(...) bytes, 16-byte aligned.  Its FIRST 64 BYTES are the
- *    library's control block (a ticket pair of the kernel tails, the device-side error record): zero them ONCE after
- *    allocating the workspace (hipMemset); every call leaves them zero, so the workspace can be reused call after call and
- *    inside hipGraph replays.  One workspace serves one stream at a time.
+ * ws / ws_bytes: scratch of bas_render_fused_workspace_bytes(...) bytes, 16-byte aligned.  Its first BAS_WS_CONTROL_BYTES (2048) are the
+ *    library's control block (arrival counters of the kernel tails, the device-side error record): zero them ONCE after
+ *    allocating the workspace (hipMemset); every call leaves the counters zero, so the workspace can be reused call after
+ *    call and inside hipGraph replays.  One workspace serves one stream at a time.
  * x must be 16-byte aligned with x_stride % 4 == 0 (BAS_E_ALIGN otherwise).
  * normalize != 0: the peak rule of make_signal_move_2d (apply_hrtf.py:462-464: m = max|y|; if m > 1: y /= m) is applied
  *    to y before the call's work on `stream` ends - inside the tail of the last kernel (no launch of its own; the workgroups
@@ -206,7 +211,8 @@ int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L);
 /* Name of the kernel bas_render_mix_fused_f32 launches for these operands, for profiling tools ("" when the sizes are
  * not served): "bas_render_fs_kernel<128>" / "<104>" / "<0>" - one workgroup of four filter and four stager waves per
  * CU, two LDS buffers (scenes with more than one (tile of 8192, source) unit per CU; <128>: L = 121 .. 128, <104>:
- * L = 97 .. 104: a unit's five row steps as one assembly block); "bas_render_fq_kernel" - four waves per tile of 2048
+ * L = 97 .. 104: a unit's five row steps as one assembly block; "<128,2>" / "<104,2>", "<128,4>" / "<104,4>": the same
+ * for subchunks of 16 / 8 samples - two / four crossfaded tap sets per row of 32 inputs); "bas_render_fq_kernel" - four waves per tile of 2048
  * outputs, staging and row steps dealt over them (small scenes: one source, a handful, real-time blocks) - or
  * "bas_render_fz_kernel<4,0>" / "<1,0>" / "<4,1>": every wave stages and filters (two workgroups of four waves per CU on
  * tiles of 8192 outputs / eight one-wave workgroups on tiles of 2048; <4,1>: chunk sizes below ~448, h-only LDS rows). */
@@ -266,8 +272,8 @@ int bas_mix_partials_f32(const float *parts, int n_parts, long part_stride, long
 
 /* The same sum, max|y| and - with normalize != 0 - the peak rule (apply_hrtf.py:462-464) in ONE launch: what the root
  * rank runs on the gathered partial mixes (bas_mix_partials_f32 + bas_scale_by_peak_f32 are a memset and two launches).
- * y and ws 16-byte aligned; ws: bas_mix_workspace_bytes() bytes whose first 64 are zero when first used (the control
- * block, as for bas_render_mix_fused_f32; a fused-render workspace may be passed). */
+ * y and ws 16-byte aligned; ws: bas_mix_workspace_bytes() bytes whose first BAS_WS_CONTROL_BYTES are zero when first
+ * used (the control block, as for bas_render_mix_fused_f32; a fused-render workspace may be passed). */
 size_t bas_mix_workspace_bytes(void);
 int bas_mix_finish_f32(const float *parts, int n_parts, long part_stride, long n, float *y, float *peak,
                        int normalize, void *ws, size_t ws_bytes, bas_stream_t stream);

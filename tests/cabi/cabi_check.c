@@ -100,7 +100,7 @@ static int check_default_path(double scale) {
     CHECK_HIP(hipMalloc((void **)&d_y, sizeof(float) * 2 * T_out));
     CHECK_HIP(hipMalloc((void **)&d_peak, sizeof(float)));
     CHECK_HIP(hipMalloc((void **)&d_H, sizeof(float) * (size_t)n_query * 2 * L));
-    CHECK_HIP(hipMemset(d_ws, 0, 64));                        /* the control block: once per workspace (include/bas.h) */
+    CHECK_HIP(hipMemset(d_ws, 0, BAS_WS_CONTROL_BYTES));      /* the control block: once per workspace (include/bas.h) */
     CHECK_HIP(hipMemcpy(d_irs, irs, sizeof(float) * 2 * NDIR * M, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(d_diffs, diffs, sizeof(double) * 2 * NDIR * NDIR, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(d_node, node_az, sizeof(float) * NDIR, hipMemcpyHostToDevice));
@@ -180,6 +180,7 @@ int main(int argc, char **argv) {
     CHECK_HIP(hipMalloc((void **)&dy, sizeof(float) * 2 * T_out));
     CHECK_HIP(hipMalloc((void **)&dpeak, sizeof(float)));
     CHECK_HIP(hipMalloc(&dws, ws_bytes));
+    CHECK_HIP(hipMemset(dws, 0, BAS_WS_CONTROL_BYTES));
     CHECK_HIP(hipMemcpy(dx, x32, sizeof(float) * n_src * T_in, hipMemcpyHostToDevice));
     CHECK_HIP(hipMemcpy(dH, H32, sizeof(float) * (size_t)n_src * n_q * 2 * L, hipMemcpyHostToDevice));
 

@@ -706,6 +706,9 @@ def test_bench_contract_line():
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
     assert "traffic" in rf and "traffic_source" in rf and rf["kernel"].startswith("bas_render_")
+    # round 4: the traffic is MEASURED by this invocation (two child runs under rocprofv3 --pmc), with its parts named
+    assert isinstance(rf["traffic"], int) and rf["traffic"] > 0, d.get("traffic_error")
+    assert rf["traffic_source"].startswith("measured in this invocation") and rf["traffic_parts"]["x"] > 0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 2 and cb["value"] > 0 and "sample" in cb and cb["unit"] == d["unit"]
     assert d["value"] > cb["value"]

@@ -255,7 +255,7 @@ def test_bench_line_round3_fields():
     before the first GPU call (its pool cannot have been forked from a process that holds the GPU)."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--sources", "4", "--seconds", "0.5", "--steps", "2",
+    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--no-traffic", "--sources", "4", "--seconds", "0.5", "--steps", "2",
                         "--warmup", "1", "--settle-ms", "20", "--cpu-sources-per-core", "1"], capture_output=True, text=True,
                        timeout=600, env=_clean_env(BAS_BENCH_MAX_CORES="2"), cwd=_root())
     assert r.returncode == 0, r.stderr[-3000:]
@@ -265,7 +265,7 @@ def test_bench_line_round3_fields():
     assert d["self_check_rel_err"] <= 1e-5 and "multi_gpu_status" in d
     assert d["cpu_baseline"]["cores"] == 2 and d["roofline"]["bound"] == "hbm"
     # the stored-IR ablation through an S = 8 scene: no fast FIR there, so no executed-flop claim
-    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--sources", "4", "--seconds", "0.5", "--steps", "2",
+    r = subprocess.run([sys.executable, os.path.join(_root(), "bench.py"), "--no-traffic", "--sources", "4", "--seconds", "0.5", "--steps", "2",
                         "--warmup", "1", "--settle-ms", "0", "--subchunk", "8", "--no-cpu-baseline"], capture_output=True,
                        text=True, timeout=600, env=_clean_env(), cwd=_root())
     assert r.returncode == 0, r.stderr[-3000:]

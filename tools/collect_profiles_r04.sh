@@ -1,0 +1,90 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (gpurun): collects the round-4 measurements DESIGN.md / README.md quote into gpurun_out/r04p/.
+# tools/publish_profiles_r04.py then copies the summaries into profiles/ (tracked).
+#   gpurun --timeout 1150 -- 'bash tools/collect_profiles_r04.sh [part ...]'      parts: core pmc shares stream misc (default: all)
+set -u
+export TMPDIR=/tmp
+O=$PWD/gpurun_out/r04p
+mkdir -p $O
+B="python3 bench.py"
+C=$PWD/binaural-audio-synthesis_amd/csrc
+PARTS="${*:-core pmc shares stream misc}"
+has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
+
+if has core; then
+  # 1. the driver's command, and a long run; the reference's default IR length; subchunks of 16 and 8 (fused / stored chunk IRs)
+  $B > $O/bench_default.json 2> $O/bench_default.err
+  $B --steps 300 --warmup 10 --no-cpu-baseline > $O/bench_300.json 2>> $O/bench_default.err
+  $B --taps 100 --steps 100 --warmup 5 --no-cpu-baseline > $O/bench_taps100.json 2>> $O/bench_default.err
+  for s in 16 8; do
+    $B --subchunk $s --steps 100 --warmup 5 --no-cpu-baseline > $O/bench_s$s.json 2>> $O/bench_default.err
+    $B --subchunk $s --unfused --steps 100 --warmup 5 --no-cpu-baseline > $O/bench_s${s}_unfused.json 2>> $O/bench_default.err
+  done
+  $B --unfused --steps 300 --warmup 10 --no-cpu-baseline > $O/bench_unfused.json 2> $O/bench_unfused.err
+  echo "[core] bench done"
+  # 2. rocprofv3 kernel stats of the same command, of the unfused path, of one source
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --steps 300 --warmup 10 --no-cpu-baseline > $O/bench_profiled.json 2> $O/prof.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_unfused -o bench -- python3 bench.py --unfused --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/prof_unfused.err
+  $B --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > $O/single_source.json 2> $O/single.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o bench -- python3 bench.py --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > /dev/null 2>> $O/single.err
+  python3 tools/single_source_latency.py > $O/single_source_latency.txt 2>&1
+  echo "[core] kernel stats done"
+fi
+
+if has pmc; then
+  # 3. PMC passes (separate runs, kernel-trace only beside them): HBM traffic of every kernel of the step, SQ counters of the FIR kernel
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_$c.err
+  done
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_SQ -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_SQ.err
+  rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_SQ2 -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_SQ2.err
+  echo "[pmc] done"
+fi
+
+if has shares; then
+  # 4. per-rank shares of the strong-scaling split on one GPU: plain launches, hipGraph, and the collective path on one rank
+  #    (--force-pg: a real RCCL communicator of size 1); kernel stats of the 32-source share; the timeline of the two streams
+  for n in 32 64 128 256; do
+    $B --sources $n --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --graph on > $O/share_${n}_graph.json 2>> $O/share.err
+    $B --sources $n --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --graph off > $O/share_${n}_plain.json 2>> $O/share.err
+    $B --sources $n --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --force-pg > $O/share_${n}_forcepg.json 2>> $O/share.err
+  done
+  for n in 27 33; do                                        # the root-weighted split of 256 sources over 8 ranks: 27 on rank 0, 33 on the others
+    $B --sources $n --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --graph on > $O/share_${n}_graph.json 2>> $O/share.err
+    $B --sources $n --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --force-pg > $O/share_${n}_forcepg.json 2>> $O/share.err
+  done
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_share32 -o bench -- python3 bench.py --sources 32 --steps 200 --warmup 10 --no-cpu-baseline --no-self-check > /dev/null 2>> $O/share.err
+  rocprofv3 --kernel-trace --output-format csv -d $O/prof_forcepg -o bench -- python3 bench.py --sources 32 --steps 40 --warmup 5 --no-cpu-baseline --no-self-check --force-pg > /dev/null 2>> $O/share.err
+  python3 tools/forcepg_timeline.py $O/prof_forcepg > $O/forcepg_timeline.txt 2>&1
+  for ch in 1 2 4 8; do
+    NCCL_MAX_NCHANNELS=$ch $B --sources 32 --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --force-pg > $O/share_32_forcepg_ch$ch.json 2>> $O/share.err
+  done
+  echo "[shares] done"
+fi
+
+if has stream; then
+  # 5. streaming: config 5 - the WHOLE hour, kernel stats of 40 blocks, the collective path on one rank, real-time sized blocks
+  $B --mode stream --sources 1024 --fs 48000 --steps 659 --warmup 3 > $O/stream_hour.json 2> $O/stream.err
+  $B --mode stream --sources 1024 --fs 48000 --steps 659 --warmup 3 --regen > $O/stream_hour_regen.json 2>> $O/stream.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o bench -- python3 bench.py --mode stream --sources 1024 --fs 48000 --steps 40 --warmup 3 > /dev/null 2>> $O/stream.err
+  $B --mode stream --sources 1024 --fs 48000 --steps 100 --warmup 3 --force-pg > $O/stream_forcepg.json 2>> $O/stream.err
+  python3 tools/stream_host_time.py 256 512 2>/dev/null > $O/stream_host_time.txt
+  python3 tools/stream_host_time.py 256 32768 2>/dev/null >> $O/stream_host_time.txt
+  echo "[stream] done"
+fi
+
+if has misc; then
+  # 6. A/B in one process: round 3's unit block (two x buffers; make -C csrc via tools/build_fir_variants.sh r03unit "--roll=0")
+  #    against the shipped rolling one; the sensitivity builds; the unit block alone (tools/ubench_unit_block.hip)
+  ( cd $C
+    [ -f libab_r03unit.so ] && for n in 256 32; do echo "== $n sources"; python3 ../../tools/ab_fir.py --sources $n --rounds 5 --reps 10 libab_r03unit.so libbas_hip.so 2>&1 | tail -2; done > $O/ab_rolling_x.txt 2>&1
+    [ -f libab_noform.so ] && python3 ../../tools/ab_fir.py --no-check --rounds 5 --reps 10 libbas_hip.so libab_noform.so libab_fma6.so libab_fma4.so libab_notaps.so libab_nowait.so 2>&1 | tail -6 > $O/ab_sensitivity.txt )
+  ( cd tools; for v in r03unit roll2 roll3 roll4 sp4 nowait notaps; do [ -x ./ubench_unit_$v ] && ./ubench_unit_$v 200 $v; done ) > $O/ubench_unit_block.txt 2>&1
+  python3 tools/stamps_fs.py 2>/dev/null > $O/stamps_fs_256.txt
+  # 7. two ranks on one device (rehearsal of the multi-rank bench path under gloo); randomised parity sweeps
+  $B --gpus 2 --steps 20 --warmup 3 > $O/bench_2ranks_one_device.json 2> $O/bench_2ranks.err
+  python3 tools/stress_fused.py 40 11 > $O/stress_fused.txt 2>&1
+  python3 tools/stress_fused.py 24 5 split > $O/stress_fused_split.txt 2>&1
+  echo "[misc] done"
+fi
+echo collected $PARTS

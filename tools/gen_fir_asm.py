@@ -361,7 +361,24 @@ def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
     r_al = r_g + 12 * nsub                                     # the crossfade weights of the row's nsub subchunks, two per pair
     last = r_al + (3 if nsub == 4 else 1)
     L = []
-    emit = L.append
+
+    def emit(ln):                                               # (sensitivity variants, wrong results: tools/build_fir_variants.sh)
+        if NOWAIT and ln.startswith("s_waitcnt") and L:
+            return
+        if NOTAPS and ln.startswith("ds_read") and "%[tap" in ln:
+            return
+        if NOX and ln.startswith("ds_read") and "%[xrow]" in ln:
+            return
+        if NOALIGN and ln.startswith(".p2align"):
+            return
+        if NOFORM and "%[" not in ln and ("op_sel_hi:[1,1,1]" in ln or f", {pr(r_al)}, " in ln or f", {pr(r_al + 2)}, " in ln
+                                          or ln.startswith("v_pk_add_f32")):
+            return
+        if FMA_KEEP < 8 and ln.startswith("v_pk_fma_f32") and f", {pr(r_al)}, " not in ln and f", {pr(r_al + 2)}, " not in ln:
+            emit.n = getattr(emit, "n", 0) + 1
+            if emit.n % 8 >= FMA_KEEP:
+                return
+        L.append(ln)
     queue = []
 
     def align():
@@ -612,14 +629,14 @@ def main():
                                  n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
                                  n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),
                                  n_wait=sum(1 for ln in ul if ln.startswith("s_waitcnt")))
-    for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY and ROLL else ()):     # subchunks of 16: two tap sets per row
-        ul, u_last = gen_unit_roll(261, lseg, 2, ROLL)
+    for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY else ()):     # subchunks of 16: two tap sets per row
+        ul, u_last = gen_unit_roll(261, lseg, 2, ROLL or 3)
         text += UNIT2_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
                                   clob=", ".join(f'"v{r}"' for r in range(U_XA, u_last + 1)),
                                   n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
                                   n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),
                                   n_wait=sum(1 for ln in ul if ln.startswith("s_waitcnt")))
-    for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY and ROLL else ()):     # subchunks of 8: four tap sets per row
+    for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY else ()):     # subchunks of 8: four tap sets per row
         ul, u_last = gen_unit_roll(261, lseg, 4, 2)
         text += UNIT4_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
                                   clob=", ".join(f'"v{r}"' for r in range(U_XA, u_last + 1)),
