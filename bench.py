@@ -184,6 +184,10 @@ def measure_traffic(args):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None, "rocprofv3 not found"
+    # never from inside a profiled process: the profiler's preloaded library may have initialised the GPU already (a child
+    # started from such a process is refused on this pool), and its environment would be inherited by the child
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCTRACER")) for k in os.environ):
+        return None, "running under a profiler: not nesting rocprofv3"
     out = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="bas_pmc_", dir="/tmp")

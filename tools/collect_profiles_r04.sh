@@ -23,10 +23,10 @@ if has core; then
   $B --unfused --steps 300 --warmup 10 --no-cpu-baseline > $O/bench_unfused.json 2> $O/bench_unfused.err
   echo "[core] bench done"
   # 2. rocprofv3 kernel stats of the same command, of the unfused path, of one source
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --steps 300 --warmup 10 --no-cpu-baseline > $O/bench_profiled.json 2> $O/prof.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_unfused -o bench -- python3 bench.py --unfused --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/prof_unfused.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o bench -- python3 bench.py --no-traffic --steps 300 --warmup 10 --no-cpu-baseline > $O/bench_profiled.json 2> $O/prof.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_unfused -o bench -- python3 bench.py --no-traffic --unfused --steps 100 --warmup 5 --no-cpu-baseline > /dev/null 2> $O/prof_unfused.err
   $B --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > $O/single_source.json 2> $O/single.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o bench -- python3 bench.py --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > /dev/null 2>> $O/single.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_single -o bench -- python3 bench.py --no-traffic --sources 1 --steps 300 --warmup 10 --no-cpu-baseline > /dev/null 2>> $O/single.err
   python3 tools/single_source_latency.py > $O/single_source_latency.txt 2>&1
   echo "[core] kernel stats done"
 fi
@@ -34,10 +34,10 @@ fi
 if has pmc; then
   # 3. PMC passes (separate runs, kernel-trace only beside them): HBM traffic of every kernel of the step, SQ counters of the FIR kernel
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_$c.err
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -o pmc -- python3 bench.py --no-traffic --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_$c.err
   done
-  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_SQ -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_SQ.err
-  rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_SQ2 -o pmc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_SQ2.err
+  rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $O/pmc_SQ -o pmc -- python3 bench.py --no-traffic --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_SQ.err
+  rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $O/pmc_SQ2 -o pmc -- python3 bench.py --no-traffic --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > /dev/null 2> $O/pmc_SQ2.err
   echo "[pmc] done"
 fi
 
@@ -53,8 +53,8 @@ if has shares; then
     $B --sources $n --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --graph on > $O/share_${n}_graph.json 2>> $O/share.err
     $B --sources $n --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --force-pg > $O/share_${n}_forcepg.json 2>> $O/share.err
   done
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_share32 -o bench -- python3 bench.py --sources 32 --steps 200 --warmup 10 --no-cpu-baseline --no-self-check > /dev/null 2>> $O/share.err
-  rocprofv3 --kernel-trace --output-format csv -d $O/prof_forcepg -o bench -- python3 bench.py --sources 32 --steps 40 --warmup 5 --no-cpu-baseline --no-self-check --force-pg > /dev/null 2>> $O/share.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_share32 -o bench -- python3 bench.py --no-traffic --sources 32 --steps 200 --warmup 10 --no-cpu-baseline --no-self-check > /dev/null 2>> $O/share.err
+  rocprofv3 --kernel-trace --output-format csv -d $O/prof_forcepg -o bench -- python3 bench.py --no-traffic --sources 32 --steps 40 --warmup 5 --no-cpu-baseline --no-self-check --force-pg > /dev/null 2>> $O/share.err
   python3 tools/forcepg_timeline.py $O/prof_forcepg > $O/forcepg_timeline.txt 2>&1
   for ch in 1 2 4 8; do
     NCCL_MAX_NCHANNELS=$ch $B --sources 32 --steps 200 --warmup 10 --no-cpu-baseline --no-self-check --force-pg > $O/share_32_forcepg_ch$ch.json 2>> $O/share.err
@@ -66,7 +66,7 @@ if has stream; then
   # 5. streaming: config 5 - the WHOLE hour, kernel stats of 40 blocks, the collective path on one rank, real-time sized blocks
   $B --mode stream --sources 1024 --fs 48000 --steps 659 --warmup 3 > $O/stream_hour.json 2> $O/stream.err
   $B --mode stream --sources 1024 --fs 48000 --steps 659 --warmup 3 --regen > $O/stream_hour_regen.json 2>> $O/stream.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o bench -- python3 bench.py --mode stream --sources 1024 --fs 48000 --steps 40 --warmup 3 > /dev/null 2>> $O/stream.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o bench -- python3 bench.py --no-traffic --mode stream --sources 1024 --fs 48000 --steps 40 --warmup 3 > /dev/null 2>> $O/stream.err
   $B --mode stream --sources 1024 --fs 48000 --steps 100 --warmup 3 --force-pg > $O/stream_forcepg.json 2>> $O/stream.err
   python3 tools/stream_host_time.py 256 512 2>/dev/null > $O/stream_host_time.txt
   python3 tools/stream_host_time.py 256 32768 2>/dev/null >> $O/stream_host_time.txt
