@@ -21,6 +21,9 @@
 #define FZ_NT_LOADS 1
 #endif
 
+#ifndef FS_PSPLIT
+#define FS_PSPLIT 1             // unit blocks of subchunks >= 32: the half-rate product P split once more (0: round 4's first form)
+#endif
 #ifndef FS_STAGER_PRIO
 #define FS_STAGER_PRIO 3        // wave priority of the stagers (latency bound: their few instructions go first) ...
 #endif
@@ -44,7 +47,9 @@ __device__ unsigned long long bas_fs_stamps[1024 * 8 * 8];
 // elsewhere and copies all 98 into and out of the pinned registers around every block.)
 // NSUB = 2 / 4: subchunks of 16 / 8 samples (the reference accepts any divisor of the chunk, apply_hrtf.py:401-402): a row
 // of 32 inputs meets two / four crossfaded tap sets; unit blocks only (ffa_unit2_asm, ffa_unit4_asm).
-template <int UNITLEN, int NSUB = 1>
+// PSPLIT (NSUB = 1, unit blocks only): the half-rate product P of the fast FIR is split once more (ffa_unitp_asm: 116
+// accumulator registers, 3.3 % fewer vector instructions per unit; DESIGN.md 4.0, profiles/r04_ubench_fast_fir_level2.txt).
+template <int UNITLEN, int NSUB = 1, int PSPLIT = 0>
 __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
     FzArgs A, const float *__restrict__ x,                   // [n_src] rows of T_in floats, stride A.x_stride
     float *__restrict__ slab,                                // [n_wg][parts_per_wg][2][tile]
@@ -137,13 +142,29 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
         // filters: lane = one row of 32 outputs of the tile, the mix over sources in 98 pinned registers
         // =========================================================================================================
         if (FS_FILTER_PRIO) __builtin_amdgcn_s_setprio(FS_FILTER_PRIO);
+        static_assert(!PSPLIT || (NSUB == 1 && UNITLEN != 0), "the P split exists for the unit blocks of subchunks >= 32");
         f32x32 accA, accB, accP;
         f32x2 accB16 = f32x2{0.f, 0.f};
+        f32x16 accPA, accPB, accPP;                          // PSPLIT: P = (PA, PB[-1 .. 7], PP) at quarter rate
+        f32x2 accPB8 = f32x2{0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 32; ++i) accA[i] = accB[i] = accP[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) accPA[i] = accPB[i] = accPP[i] = 0.f;
         float *slab_wg = slab + (long)blockIdx.x * A.parts_per_wg * 2 * TILE;
         auto flush = [&](long t) {
             f32x2 acc[32];
+            if constexpr (PSPLIT) {                          // P[2r] = PA[r] + PB[r-1];  P[2r+1] = PP[r] - PA[r] - PB[r]
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const f32x2 a = f32x2{accPA[2 * r], accPA[2 * r + 1]}, b0 = f32x2{accPB[2 * r], accPB[2 * r + 1]};
+                    const f32x2 b1 = r < 7 ? f32x2{accPB[2 * r + 2], accPB[2 * r + 3]} : accPB8;
+                    const f32x2 pp = f32x2{accPP[2 * r], accPP[2 * r + 1]};
+                    const f32x2 pe = a + b0, po = (pp - a) - b1;
+                    accP[4 * r] = pe.x; accP[4 * r + 1] = pe.y;
+                    accP[4 * r + 2] = po.x; accP[4 * r + 3] = po.y;
+                }
+            }
 #pragma unroll
             for (int p = 0; p < 16; ++p) {                   // y[2p] = A[p] + B[p-1];  y[2p+1] = P[p] - A[p] - B[p]
                 const f32x2 a = f32x2{accA[2 * p], accA[2 * p + 1]}, b0 = f32x2{accB[2 * p], accB[2 * p + 1]};
@@ -155,6 +176,11 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
 #pragma unroll
             for (int i = 0; i < 32; ++i) accA[i] = accB[i] = accP[i] = 0.f;
             accB16 = f32x2{0.f, 0.f};
+            if constexpr (PSPLIT) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) accPA[i] = accPB[i] = accPP[i] = 0.f;
+                accPB8 = f32x2{0.f, 0.f};
+            }
             if (A.direct) {                                  // uniform
                 const long n0 = t * TILE + 2048 * wv + 32 * lane0;       // this lane's first output
                 const float lmax = fz_store_row_direct(acc, y, A.T_out, n0, A.accumulate, false);
@@ -231,7 +257,10 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
                         sl -= 1;
                     }
                 }
-                if constexpr (NSUB == 4)                     // (the weights of a row's subchunks: al + u S / K, formed in the block)
+                if constexpr (PSPLIT)
+                    ffa_unitp_asm<XR, UNITLEN>(accA, accB, accPA, accPB, accPB8, accPP, accB16,
+                                               (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv);
+                else if constexpr (NSUB == 4)                // (the weights of a row's subchunks: al + u S / K, formed in the block)
                     ffa_unit4_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv,
                                                (float)A.S * A.invK);
                 else if constexpr (NSUB == 2)
@@ -497,7 +526,11 @@ hipError_t bas_fs_launch(const FzArgs &A, const float *x, float *slab, const flo
 #if FZ_ASM
     typedef void (*fs_fn)(FzArgs, const float *, float *, const float *, const unsigned *, float *, unsigned int *);
     const int ul = bas_fs_unit_len(A.Lp);
+#if FS_PSPLIT
+    fs_fn fn = ul == 128 ? bas_render_fs_kernel<128, 1, 1> : ul == 104 ? bas_render_fs_kernel<104, 1, 1> : bas_render_fs_kernel<0>;
+#else
     fs_fn fn = ul == 128 ? bas_render_fs_kernel<128> : ul == 104 ? bas_render_fs_kernel<104> : bas_render_fs_kernel<0>;
+#endif
     if (A.S == 16 || A.S == 8) {                             // (the plan gives these to this kernel only with a unit block)
         if (ul == 0) return hipErrorNotSupported;
         fn = A.S == 16 ? (ul == 128 ? bas_render_fs_kernel<128, 2> : bas_render_fs_kernel<104, 2>)

@@ -102,3 +102,26 @@ def test_vectorized_trajectory_that_cannot_broadcast_falls_back(monkeypatch):
     with pytest.raises(Stop):
         bas.apply_hrtf.make_signal_move_2d(np.zeros(2000, dtype=np.float32), 512, 32, traj, object(), vectorized=True)
     assert np.ndarray in calls and int in calls             # tried the array call, then called chunk by chunk
+
+
+@pytest.mark.parametrize("lseg,nsub,nbuf,psplit", [(128, 1, 3, False), (104, 1, 3, False), (128, 1, 2, True), (104, 1, 2, True),
+                                                   (128, 2, 3, False), (104, 2, 3, False), (128, 4, 2, False), (104, 4, 2, False),
+                                                   (128, 1, 2, False), (128, 1, 4, False)])
+def test_generated_unit_blocks_compute_the_fir(lseg, nsub, nbuf, psplit):
+    """tools/emulate_fir_asm.py executes the instruction list tools/gen_fir_asm.py writes for a unit block - LDS reads with
+    the in-order return queue and the s_waitcnt counts, packed FMAs with op_sel - on random rows and taps (float64), combines
+    the accumulators the way the flush does and compares with the defining sum (apply_hrtf.py:442-446): every variant the
+    library ships (rolling x row; the P product split once more; two and four tap sets per row for subchunks of 16 / 8; both
+    segment lengths) computes the FIR to 1e-12, and no register is read while a read into it is in flight."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import emulate_fir_asm as emu
+    import gen_fir_asm as gen
+    lines, last = gen.gen_unit_roll(261, lseg, nsub, nbuf, psplit=psplit)
+    assert last + 11 + 12 <= 256                             # operands + what hipcc keeps around the block still fit a wave
+    y, want = emu.run(lines, 261, lseg, nsub, psplit, seed=lseg + 7 * nsub)
+    assert np.abs(y - want).max() <= 1e-12 * np.abs(want).max()
+    if not psplit and nsub == 1:                             # round 3's block (two x buffers) through the same interpreter
+        y0, want0 = emu.run(gen.gen_unit(261, lseg), 261, lseg, 1, False, seed=lseg + 7 * nsub)
+        assert np.abs(y0 - want0).max() <= 1e-12 * np.abs(want0).max() and np.array_equal(want0, want)

@@ -354,11 +354,26 @@ def gen_unit(xr_stride, lseg):
 R_X, R_XS, R_T0 = 98, 130, 146
 
 
-def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
+def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2, psplit=False):
+    """psplit: the half-rate product P = (g_e + g_o) * (x_e + x_o) is split ONCE MORE the same way (a second fast-FIR level
+    for one of the three products: what the registers of the rolling x row allow; profiles/r04_ubench_fast_fir_level2.txt):
+    with xs = x_e + x_o, gs = g_e + g_o at half rate,  P[2r] = PA[r] + PB[r-1],  P[2r+1] = PP[r] - PA[r] - PB[r],
+    PA = gs_even * xs_even, PB = gs_odd * xs_odd, PP = (gs_even + gs_odd) * (xs_even + xs_odd) at quarter rate: a half octet
+    carries ONE quarter-rate tap (its two half-rate taps are the even and the odd one), so its 2 x 16 P FMAs become
+    8 + 9 + 8 at the most.  Accumulators: A v[0:31], B v[32:63], PA v[64:79], PB v[80:97] (r = -1 .. 7), PP v[98:113],
+    B entry 16 v[114:115]; the operands start at v116."""
+    assert not (psplit and nsub != 1)
     U_STEPS = unit_steps(lseg)
     halo = len(U_STEPS) - 1
+    R_X = 116 if psplit else 98                                 # (shadow the module's register map: 18 more accumulators)
+    R_XS = R_X + 32
+    R_XSS = R_XS + 16                                           # psplit: xs_even + xs_odd, 8 values
+    R_T0 = R_XS + 16 + (8 if psplit else 0)
+    PA0, PB0, PP0 = 64, 80, 98
+    b16 = 114 if psplit else B16
     r_g = R_T0 + 16 * nbuf                                     # formed taps: nsub x (ge[2], go[2], gs[2]) pairs
-    r_al = r_g + 12 * nsub                                     # the crossfade weights of the row's nsub subchunks, two per pair
+    r_gss = r_g + 12 * nsub                                    # psplit: gs_even + gs_odd of the half octet
+    r_al = r_gss + (2 if psplit else 0)                        # the crossfade weights of the row's nsub subchunks, two per pair
     last = r_al + (3 if nsub == 4 else 1)
     L = []
 
@@ -422,9 +437,25 @@ def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
                 if p >= 0:
                     lines.append(f"v_pk_fma_f32 {pr(A0 + 2 * p)}, {pr(ge + 2 * k)}, {xp}, {pr(A0 + 2 * p)} op_sel_hi:[1,0,1]")
                     sel = "op_sel:[0,1,0]" if xs_hi else "op_sel_hi:[1,0,1]"
-                    lines.append(f"v_pk_fma_f32 {pr(P0 + 2 * p)}, {pr(gs + 2 * k)}, {xsp}, {pr(P0 + 2 * p)} {sel}")
-                breg = B16 if p + 1 == 16 else B0 + 2 * (p + 1)
+                    if not psplit:
+                        lines.append(f"v_pk_fma_f32 {pr(P0 + 2 * p)}, {pr(gs + 2 * k)}, {xsp}, {pr(P0 + 2 * p)} {sel}")
+                breg = b16 if p + 1 == 16 else B0 + 2 * (p + 1)
                 lines.append(f"v_pk_fma_f32 {pr(breg)}, {pr(go + 2 * k)}, {xp}, {pr(breg)} op_sel:[0,1,0]")
+        if psplit:                                              # the quarter-rate tap j of this half octet against xs_even / xs_odd / their sum
+            j = 2 * i + h - 8
+            gs = r_g + 8
+            for r_ in range(-1, 8):
+                t = r_ - j
+                if not (0 <= t < 8):
+                    continue
+                quads.add(t)
+                xs_pair = pr(R_XS + 2 * t)                      # (xs[2t], xs[2t+1]) = (xs_even[t], xs_odd[t])
+                xss_pair, xss_hi = pr(R_XSS + 2 * (t >> 1)), t & 1
+                if r_ >= 0:
+                    lines.append(f"v_pk_fma_f32 {pr(PA0 + 2 * r_)}, {pr(gs)}, {xs_pair}, {pr(PA0 + 2 * r_)} op_sel_hi:[1,0,1]")
+                    sel = "op_sel:[0,1,0]" if xss_hi else "op_sel_hi:[1,0,1]"
+                    lines.append(f"v_pk_fma_f32 {pr(PP0 + 2 * r_)}, {pr(r_gss)}, {xss_pair}, {pr(PP0 + 2 * r_)} {sel}")
+                lines.append(f"v_pk_fma_f32 {pr(PB0 + 2 * (r_ + 1))}, {pr(gs + 2)}, {xs_pair}, {pr(PB0 + 2 * (r_ + 1))} op_sel:[0,1,0]")
         return lines, quads, sets
 
     plan = [fma_list(*hv) for hv in halves]
@@ -454,6 +485,8 @@ def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
                 emit(f"v_pk_fma_f32 {pr(go + 2 * k)}, {pr(to + 2)}, {wp}, {pr(to)} {wsel}")
             for k in range(2):
                 emit(f"v_pk_add_f32 {pr(gs + 2 * k)}, {pr(ge + 2 * k)}, {pr(go + 2 * k)}")
+        if psplit:
+            emit(f"v_pk_add_f32 {pr(r_gss)}, {pr(r_g + 8)}, {pr(r_g + 10)}")
 
     # x quads of step r + 1 go out right behind the half octet that uses quad c of step r for the last time
     x_after = {}                                                # half index n -> reads issued in front of the FMAs of half n
@@ -485,6 +518,8 @@ def gen_unit_roll(xr_stride, lseg, nsub=1, nbuf=2):
                 xs_done.add((rm, c))
                 for q in (2 * c, 2 * c + 1):
                     emit(f"v_add_f32_e64 v{R_XS + q}, v{R_X + 2 * q}, v{R_X + 2 * q + 1}")
+                if psplit:
+                    emit(f"v_add_f32_e64 v{R_XSS + c}, v{R_XS + 2 * c}, v{R_XS + 2 * c + 1}")
 
     for n, ((r, i, h), (lines, quads, sets)) in enumerate(zip(halves, plan)):
         nxt = min([m for m in wait_points if m > n], default=len(halves))
@@ -542,6 +577,29 @@ __device__ __forceinline__ void ffa_unit_asm<{xr}, {lseg}>(f32x32 &accA, f32x32 
 }}
 """
 
+
+PSPLIT_NBUF = 2
+UNITP_FUNC = """
+// The same unit with the half-rate product P split once more (gen_unit_roll: psplit): {n_fma} v_pk_fma_f32, {n_ds} ds_read_b128,
+// {n_wait} waits.  116 accumulator registers: A, B as before, PA v[64:79], PB v[80:97] (entries r = -1 .. 7), PP v[98:113],
+// B entry 16 v[114:115]; the flush combines P[2r] = PA[r] + PB[r-1], P[2r+1] = PP[r] - PA[r] - PB[r] first.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int XR, int LSEG>
+__device__ __forceinline__ void ffa_unitp_asm(f32x32 &accA, f32x32 &accB, f32x16 &accPA, f32x16 &accPB, f32x2 &accPB8, f32x16 &accPP,
+                                               f32x2 &accB16, unsigned xrow4, const unsigned (&tap)[5], const float (&al)[5]);
+template <>
+__device__ __forceinline__ void ffa_unitp_asm<{xr}, {lseg}>(f32x32 &accA, f32x32 &accB, f32x16 &accPA, f32x16 &accPB, f32x2 &accPB8,
+                                               f32x16 &accPP, f32x2 &accB16, unsigned xrow4, const unsigned (&tap)[5],
+                                               const float (&al)[5]) {{
+    asm volatile(
+{body}
+        : "+{{v[0:31]}}"(accA), "+{{v[32:63]}}"(accB), "+{{v[64:79]}}"(accPA), "+{{v[80:95]}}"(accPB), "+{{v[96:97]}}"(accPB8),
+          "+{{v[98:113]}}"(accPP), "+{{v[114:115]}}"(accB16)
+        : [xrow] "v"(xrow4), [tap0] "v"(tap[0]), [tap1] "v"(tap[1]), [tap2] "v"(tap[2]), [tap3] "v"(tap[3]), [tap4] "v"(tap[4]),
+          [al0] "v"(al[0]), [al1] "v"(al[1]), [al2] "v"(al[2]), [al3] "v"(al[3]), [al4] "v"(al[4])
+        : "memory", {clob});
+}}
+"""
 
 UNIT2_FUNC = """
 // The same unit for subchunks of 16 samples (apply_hrtf.py:401-402 accepts any divisor of the chunk; :442-443): inputs 0-15 of
@@ -629,6 +687,13 @@ def main():
                                  n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
                                  n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),
                                  n_wait=sum(1 for ln in ul if ln.startswith("s_waitcnt")))
+    for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY else ()):     # the P product split once more (fast-FIR level 1.5)
+        ul, u_last = gen_unit_roll(261, lseg, 1, PSPLIT_NBUF, psplit=True)
+        text += UNITP_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
+                                  clob=", ".join(f'"v{r}"' for r in range(116, u_last + 1)),
+                                  n_fma=sum(1 for ln in ul if ln.startswith("v_pk_fma")),
+                                  n_ds=sum(1 for ln in ul if ln.startswith("ds_read")),
+                                  n_wait=sum(1 for ln in ul if ln.startswith("s_waitcnt")))
     for lseg in (U_LSEGS if 261 in xrs and not GENERIC_ONLY else ()):     # subchunks of 16: two tap sets per row
         ul, u_last = gen_unit_roll(261, lseg, 2, ROLL or 3)
         text += UNIT2_FUNC.format(xr=261, lseg=lseg, body="\n".join(f'        "{ln}\\n\\t"' for ln in ul),
