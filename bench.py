@@ -788,6 +788,9 @@ def main():
         # the 2-parallel fast FIR row step (3/4 of the multiplications) serves subchunks that are multiples of 32,
         # in the fused kernel and in the stored-IR hd kernel; the other kernels execute the direct form
         fast_fir = s % 32 == 0 and (sc.fused_used or sc.kernel == "bas_render_hd_kernel")
+        # executed packed multiply-adds per 128-tap unit against the direct form's 4096 + 256 (FIR + crossfade forming): level 1 of
+        # the fast FIR 3136 + 384; the unit blocks of the split-role kernel (level 1.5: the product P split once more) 2912 + 448
+        exec_ratio = ((2912 + 448) if sc.kernel in ("bas_render_fs_kernel<128>", "bas_render_fs_kernel<104>") else (3136 + 384)) / (4096 + 256)
         traffic, traffic_source, traffic_parts = None, None, None
         # what the FIR kernel must move, by part (bytes per launch): x windows (each (tile, source) unit reads its tile + a
         # 128-sample halo), read plans (288 B per chunk IR, tile's chunks + 2 per unit), the packed table (once per XCD L2 at
@@ -854,12 +857,13 @@ def main():
                          "kernel_ms": fir_ms, "algorithmic_bytes": algo_bytes},
             "valu": {"achieved": algo_flops / fir_s / 1e12, "peak": FP32_VALU_PEAK_TF, "unit": "TFLOP/s",
                      "frac": algo_flops / fir_s / 1e12 / FP32_VALU_PEAK_TF,
-                     **({"executed": algo_flops * (3136 + 384) / (4096 + 256) / fir_s / 1e12,
-                         "frac_executed": algo_flops * (3136 + 384) / (4096 + 256) / fir_s / 1e12 / FP32_VALU_PEAK_TF}
+                     **({"executed": algo_flops * exec_ratio / fir_s / 1e12,
+                         "frac_executed": algo_flops * exec_ratio / fir_s / 1e12 / FP32_VALU_PEAK_TF}
                         if fast_fir else {}),
                      "note": "the FIR is 128 flop/B: fp32-VALU bound, HBM fraction tops out near 15 %.  achieved = direct-form "
-                             "arithmetic (4 L flop per source sample) per second; the row step is a 2-parallel fast FIR and "
-                             "executes 3/4 of those multiplications plus forming (executed).  peak is nominal (2.4 GHz): a "
+                             "arithmetic (4 L flop per source sample) per second; the row step is a 2-parallel fast FIR (its product "
+                             "P split once more in the split-role kernel's unit blocks) and executes 3/4 (0.71) of those "
+                             "multiplications plus forming (executed).  peak is nominal (2.4 GHz): a "
                              "bare v_pk_fma_f32 stream on random operands sustains ~122 TFLOP/s (power-limited clock; "
                              "profiles/r02_ubench_fir_pattern.txt, DESIGN.md 4.1)"},
         }

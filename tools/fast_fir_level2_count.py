@@ -69,8 +69,9 @@ def main():
     print("Registers of the shipped unit block: 98 accumulators + 32 x + 16 sums + 48 taps + 12 formed + 2 = 208 (+ 11 operands).")
     print("Level 2 on 32-output rows: ~156 accumulators + 72 x-side + 18 formed + 32 taps = 278 > 256: does not exist.")
     print("Level 1.5: 116 accumulators + 56 x-side + 14 formed + 32 taps + 2 = 220 (+ 11): fits since the rolling x row, and")
-    print("  saves 3.6 % of the vector instructions = 2.3 % of the kernel time by the measured slope - for a new accumulator layout in")
-    print("  every kernel that shares the flush.  Not built.")
+    print("  saves 3.6 % of the vector instructions = 2.3 % of the kernel time by the measured slope.  BUILT (ffa_unitp_asm, the")
+    print("  unit blocks of subchunks >= 32: 3 485 instead of 3 605 instructions per unit with the block's corners): -2.5 % kernel")
+    print("  time measured (profiles/r04_ab_psplit.txt) - the slope's prediction.")
     print("Level 2 on 16-output rows (84 accumulators: two filter waves per SIMD would fit): forming and tap sums per output")
     print("  double, so a 32 x 32 block costs 7.7 % MORE vector instructions than the shipped form, and 1.5 x the tap reads (a tap")
     print("  read costs the kernel what 1.83 vector instructions do): slower by the measured prices.  Not built.")
