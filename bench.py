@@ -13,9 +13,9 @@ spiral / askew-circle trajectories, mixed to one stereo pair.  
 the reference's make_signal_move_2d path over that scene with inputs resident in HBM when the timed region
 starts - the audio AND the trajectories (elev, azim per chunk boundary, float64):
 
-    bas_traj_params_f64        a3: angles -> (4 directions, 3 weights) per chunk boundary (sphere.py:78-121,
-                               apply_hrtf.py:199-215, :261-266)
-    bas_interp2d_plan_f32      delays, shift splits, folded blend weights (apply_hrtf.py:219-279)
+    bas_interp2d_plan_angles_f32   a3: angles -> (4 directions, 3 weights) per chunk boundary (sphere.py:78-121,
+                               apply_hrtf.py:199-215, :261-266), and in the same launch the read plans: delays, shift splits,
+                               folded blend weights (apply_hrtf.py:219-279)
     bas_render_mix_fused_f32   chunk IRs from the table + time-varying FIR + overlap-add + mix + max|y| + the peak rule
                                (apply_hrtf.py:462-464) in the tail of its last kernel
     [N>1: one RCCL gather of the un-normalised partial mixes to rank 0; there bas_mix_finish_f32: fixed-order sum +

@@ -319,7 +319,8 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     return y, peak
 
 
-MERGED_A3_MAX_QUERIES = 65536       # below this a3 rides inside the plan kernel (one launch less; see bas.h)
+MERGED_A3_MAX_QUERIES = 1 << 30     # a3 rides inside the plan kernel (one launch less; see bas.h) for every batch size since round 4:
+                                    # the angle arithmetic is done once per query by half of a block's waves and handed over through LDS
 
 
 def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize="mix", out=None, events=None,
@@ -329,9 +330,10 @@ def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize=
     bas_traj_params_f64 (a3 + the elevation bracket), then render_params_device (read plans + fused FIR where the
     sizes allow it).  `params` = optional (idx [n, 4] int32, w [n, 3] float64) buffers to write the parameters
     into (no allocation per call).  Returns (y [2, T_out], peak).
-    Batches of at most MERGED_A3_MAX_QUERIES queries run a3 inside the plan kernel (bas_interp2d_plan_angles_f32: one
-    launch less); above that both ears' threads redoing the angle arithmetic cost more than the launch (221 k queries:
-    53 us merged against 9 + 15 us)."""
+    a3 runs inside the plan kernel (bas_interp2d_plan_angles_f32: one launch less, no (idx, w) round trip; round 3's form,
+    in which both ears' threads redid the angle arithmetic, lost above 65 536 queries - 53 us against 9 + 15 us for 221 k;
+    round 4's does it once per query: equal there, 3 us ahead for a 32-source share: tools/ab_a3_merge.py).  `params` is
+    only written by the two-launch form (MERGED_A3_MAX_QUERIES = 0)."""
     tbl = as_device_table(tbl)
     n_src, t_in = x.shape
     if elev.numel() != n_src * (t_in // chunksize + 1) or azim.numel() != elev.numel():

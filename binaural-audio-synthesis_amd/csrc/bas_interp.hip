@@ -271,7 +271,29 @@ __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__
         ix[0] = idx[4 * q + 0]; ix[1] = idx[4 * q + 1]; ix[2] = idx[4 * q + 2]; ix[3] = idx[4 * q + 3];
         wt[0] = w[3 * q + 0]; wt[1] = w[3 * q + 1]; wt[2] = w[3 * q + 2];
     } else {
-        traj_params_one<ANG == 2>(PA.R, PA.node_az, PA.elev[q], PA.azim[q], ix, wt);
+        // a3 for the block's 128 queries by its first two waves (one query per lane: the angle arithmetic is done once per
+        // query, as in the separate kernel), handed to the four waves' (query, ear) threads through LDS.  Round 3 had every
+        // (query, ear) thread redo it: 53 us for 221 k queries against 9 + 15 for two kernels; this form: both in one launch
+        // with no (idx, w) round trip through HBM.
+        __shared__ int s_ix[128][4];
+        __shared__ double s_wt[128][3];
+        if (threadIdx.x < 128) {                              // (waves 0 and 1: uniform per wave)
+            long qq = blockIdx.x * 128L + threadIdx.x;
+            if (qq >= n) qq = n - 1;
+            int jx[4];
+            double wv[3];
+            traj_params_one<ANG == 2>(PA.R, PA.node_az, PA.elev[qq], PA.azim[qq], jx, wv);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_ix[threadIdx.x][i] = jx[i];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s_wt[threadIdx.x][i] = wv[i];
+        }
+        __syncthreads();
+        const int ql = (int)(q - blockIdx.x * 128L);          // (the clamped tail threads of the last block: its last query)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ix[i] = s_ix[ql][i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) wt[i] = s_wt[ql][i];
     }
     const int pt = clamp_dir(ix[0], ndir), qt = clamp_dir(ix[1], ndir);
     const int pb = clamp_dir(ix[2], ndir), qb = clamp_dir(ix[3], ndir);

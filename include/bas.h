@@ -199,8 +199,9 @@ int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, const double 
                           int ndir, int L, int U, void *plans, size_t plans_bytes,
                           bas_stream_t stream);
 /* bas_traj_params_branch_f64 + bas_interp2d_plan_f32 in ONE launch (a3 and the plan step of a6: sphere.py:78-121,
- * apply_hrtf.py:199-279), for small batches where a launch costs more than the arithmetic (one source x 10 s is 863
- * queries; a real-time block of 256 sources is 768): both ears' threads of a query redo the angle arithmetic.
+ * apply_hrtf.py:199-279): the first two waves of a block do the angle arithmetic of its 128 queries, the (query, ear)
+ * threads of all four take the parameters from LDS - no (idx, w) round trip through HBM, one launch less (what every
+ * render from angles runs since round 4; one source x 10 s is 863 queries, the headline scene 221 k).
  * Same plans, bit for bit, as the two calls.  elev / azim [n] f64 device; ring_* host, node_az device, branch as in
  * bas_traj_params_branch_f64. */
 int bas_interp2d_plan_angles_f32(const double *diffs, const double *elev, const double *azim, int n,
