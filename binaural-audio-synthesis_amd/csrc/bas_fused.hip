@@ -870,7 +870,7 @@ static int fused_impl(const char *who, int phases, const float *x, long x_stride
         // rescale by another workgroup would need - those leave the L2 one by one: the four-wave kernel took 29 us instead
         // of 14 for one source x 10 s (profiles/r04_ab_kernel_tails.txt).  The rule stays a launch of its own here.
         if (p.n_wg <= BAS_TAIL_MAX_WG) {
-            A.tail_mode = 1;                                 // k_last = 1, no rule
+            A.tail_mode = 1;                                 // max|y| only
         } else if (phases & 1) {                             // more workgroups than maxima slots: they max into a cleared word
             hipError_t e = hipMemsetAsync(peak_dev, 0, sizeof(float), st);
             if (e != hipSuccess) return bas_fail((int)e, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));

@@ -1038,16 +1038,6 @@ hipError_t bas_allow_full_lds(const void *fn) {
     return hipSuccess;
 }
 
-// how many late workgroups share the rescale of the peak rule (bas_tail.h): they wait for each other, so no more than a
-// fraction of what even a partitioned chip holds at once
-unsigned bas_tail_k_last(unsigned n_wg, int normalize) {
-    if (!normalize) return 1u;
-    unsigned k = (unsigned)bas_device_cus() / 8u;
-    if (k < 1u) k = 1u;
-    if (k > 32u) k = 32u;
-    return n_wg < k ? n_wg : k;
-}
-
 // slabs of partial tiles -> y (fixed order), fused max|y|: shared by the FIR launchers (bas_fused.hip too).
 // tail != null (fused entry points): tail->ctl / wgpeak / y / n / peak / normalize are filled in, the launch geometry here;
 // the kernel then ends in bas_tail.  Launches with more workgroups than the control area has maxima slots keep the round-3
@@ -1063,7 +1053,6 @@ int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per
         if (tail && 2 * blocks_per_ear <= BAS_TAIL_MAX_WG) {
             T = *tail;
             T.n_wg = (unsigned)(2 * blocks_per_ear);
-            T.k_last = bas_tail_k_last(T.n_wg, T.normalize);
             if (tail_skipped) *tail_skipped = 0;
         }
         hipLaunchKernelGGL(bas_slab_reduce_wide_kernel, dim3((unsigned)(2 * blocks_per_ear)), dim3(256), 0, st, slab, tile,
@@ -1074,7 +1063,6 @@ int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per
     if (tail && grid <= BAS_TAIL_MAX_WG) {
         T = *tail;
         T.n_wg = (unsigned)grid;
-        T.k_last = bas_tail_k_last(T.n_wg, T.normalize);
         if (tail_skipped) *tail_skipped = 0;
     }
     hipLaunchKernelGGL(bas_slab_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, tile,
@@ -1365,7 +1353,6 @@ extern "C" int bas_mix_finish_f32(const float *parts, int n_parts, long part_str
     T.y = y; T.n = n; T.peak = peak; T.normalize = normalize ? 1 : 0;
     const int grid = bas_grid_for((n + 3) / 4, 2048);
     T.n_wg = (unsigned)grid;
-    T.k_last = bas_tail_k_last(T.n_wg, T.normalize);
     hipLaunchKernelGGL(bas_mix_finish_kernel, dim3(grid), dim3(256), 0, st, parts, n_parts, part_stride, n, y, T);
     return bas_check_launch("bas_mix_finish_f32");
 }

@@ -33,7 +33,6 @@ struct BasTail {
     long n;
     float *peak;                // receives max|y| before the rule (may be null)
     unsigned n_wg;              // workgroups of this launch that call bas_tail
-    unsigned k_last;            // unused (kept for the launchers' bookkeeping: 1 = no rule in the tail)
     int normalize;              // apply the rule
 };
 
@@ -165,5 +164,3 @@ __device__ __forceinline__ void bas_tail(const BasTail &T, float lmax) {
     }
 }
 
-// host side: how many late workgroups share the rescale (bas_render.hip)
-unsigned bas_tail_k_last(unsigned n_wg, int normalize);
