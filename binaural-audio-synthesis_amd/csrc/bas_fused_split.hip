@@ -202,9 +202,19 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             }
         };
         long open_tile = -1;                                 // tile whose partial sums the accumulators hold
+        // Unit blocks: the lane's five tap rows, crossfade weights and x row depend on the TILE (where its window starts
+        // inside a chunk), not on the source: they are worked out when the tile changes (a uniform branch; ~100 vector
+        // instructions, six of them quarter-rate integer multiplies, that round 4's first builds issued in front of every
+        // unit - 3 % of a unit's vector instructions) and kept as LDS addresses; per unit they move to the other buffer in
+        // place (six adds).  The block's operands live in registers across it anyway.
+        long addr_tile = -1;
+        int addr_buf = 0;                                    // the LDS buffer the addresses below point into
+        unsigned tapv[5] = {0u, 0u, 0u, 0u, 0u}, xrow4 = 0u;
+        float alv[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, blv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        const unsigned buf_bytes = 16u * (unsigned)buf4;
         for (long pid = 0; pid < n_pass; ++pid) {
             // the thread index is made opaque once per unit: what derives from it is recomputed per unit instead of being
-            // held in (or spilled from) registers across the row steps
+            // held in (or spilled from) registers across the row steps (per-step blocks; the unit blocks: per tile)
             int tid = tid0;
             asm volatile("" : "+v"(tid));
             const int lane = tid & 63;
@@ -214,6 +224,47 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             if (tile != open_tile) {                         // the accumulators belong to another tile: hand them over
                 if (open_tile >= 0) flush(open_tile);        // (in front of the barrier: under the stagers' work)
                 open_tile = tile;
+            }
+            auto weight = [&](int m) {                       // crossfade weight of the subchunk that holds offset m of its chunk
+                if (A.s_pow2) return (float)(m & ~(A.S - 1)) * A.invK;
+                int q = (int)((float)m * A.invS);            // any multiple of 32: m / S by float estimate, corrected
+                const int r = m - q * A.S;
+                if (r < 0) q -= 1;
+                if (r >= A.S) q += 1;
+                return (float)(q * A.S) * A.invK;
+            };
+            if constexpr (UNITLEN != 0) {
+                const int cur_buf = (int)(pid & 1);
+                if (tile == addr_tile && cur_buf != addr_buf) {              // (uniform) same rows, the other buffer: in place
+                    const unsigned delta = cur_buf ? buf_bytes : 0u - buf_bytes;
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) tapv[r] += delta;
+                    xrow4 += delta;
+                    addr_buf = cur_buf;
+                }
+                if (tile != addr_tile) {                     // (uniform; one tap segment per unit: the window depends on the tile alone)
+                    addr_tile = tile;
+                    addr_buf = cur_buf;
+                    const unsigned bufb = (unsigned)reinterpret_cast<uintptr_t>(lds4 + cur_buf * buf4);
+                    const int row_out = 64 * wv + lane + G.halo;             // window row holding the lane's outputs
+                    const int pos = G.mo0 + 32 * row_out;
+                    int sl = (int)((float)pos * A.invK);                     // chunk slot of that row (float estimate, corrected)
+                    int m_in = pos - sl * A.K;                               // offset of the row inside its chunk
+                    if (m_in < 0) { m_in += A.K; sl -= 1; }
+                    if (m_in >= A.K) { m_in -= A.K; sl += 1; }
+                    xrow4 = bufb + 16u * (unsigned)(row_out - 4);            // the x row of step 4 (step r reads 16 (4 - r) bytes above)
+                    unsigned tap = bufb + 4u * (unsigned)(XFLOATS + sl * HD_SLOT - 32 * 4);   // tap row of step 0
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        alv[r] = weight(m_in);
+                        if constexpr (NSUB == 2) blv[r] = weight(m_in + 16);   // inputs 16-31 of the row: the next subchunk
+                        tapv[r] = tap;
+                        m_in -= 32;
+                        const bool wrap = m_in < 0;                          // the next row up lies in the chunk before: one slot down
+                        m_in += wrap ? A.K : 0;
+                        tap += 32u * 16u - (wrap ? 4u * (unsigned)HD_SLOT : 0u);
+                    }
+                }
             }
 #ifdef BAS_STAMPS
             const unsigned long long t1 = FS_NOW();
@@ -225,49 +276,27 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             const f32x4 *xs4 = lds4 + (pid & 1) * buf4;
             const float *hd = reinterpret_cast<const float *>(xs4) + XFLOATS;
             const int Lseg = G.Lseg, halo = G.halo;
-            const int row_out = 64 * wv + lane + halo;       // window row holding the lane's outputs
-            const int pos = G.mo0 + 32 * row_out;
-            int sl = (int)((float)pos * A.invK);             // chunk slot of that row (float estimate, corrected)
-            int m_in = pos - sl * A.K;                       // offset of the row inside its chunk
-            if (m_in < 0) { m_in += A.K; sl -= 1; }
-            if (m_in >= A.K) { m_in -= A.K; sl += 1; }
-            const f32x4 *xrow = xs4 + row_out;
 #ifdef BAS_STAMPS
             const unsigned long long c0 = __builtin_amdgcn_s_memtime();
 #endif
-            auto weight = [&](int m) {                       // crossfade weight of the subchunk that holds offset m of its chunk
-                if (A.s_pow2) return (float)(m & ~(A.S - 1)) * A.invK;
-                int q = (int)((float)m * A.invS);            // any multiple of 32: m / S by float estimate, corrected
-                const int r = m - q * A.S;
-                if (r < 0) q -= 1;
-                if (r >= A.S) q += 1;
-                return (float)(q * A.S) * A.invK;
-            };
             if constexpr (UNITLEN != 0) {                    // a whole segment of UNITLEN taps: its five row steps in one block
-                unsigned tapv[5];
-                float alv[5], blv[5];
-#pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    alv[r] = weight(m_in);
-                    if constexpr (NSUB == 2) blv[r] = weight(m_in + 16);     // inputs 16-31 of the row: the next subchunk
-                    tapv[r] = (unsigned)reinterpret_cast<uintptr_t>(hd + sl * HD_SLOT + (32 * r - 32) * 4);
-                    m_in -= 32;
-                    if (m_in < 0) {
-                        m_in += A.K;
-                        sl -= 1;
-                    }
-                }
                 if constexpr (PSPLIT)
-                    ffa_unitp_asm<XR, UNITLEN>(accA, accB, accPA, accPB, accPB8, accPP, accB16,
-                                               (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv);
+                    ffa_unitp_asm<XR, UNITLEN>(accA, accB, accPA, accPB, accPB8, accPP, accB16, xrow4, tapv, alv);
                 else if constexpr (NSUB == 4)                // (the weights of a row's subchunks: al + u S / K, formed in the block)
-                    ffa_unit4_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv,
-                                               (float)A.S * A.invK);
+                    ffa_unit4_asm<XR, UNITLEN>(accA, accB, accB16, accP, xrow4, tapv, alv, (float)A.S * A.invK);
                 else if constexpr (NSUB == 2)
-                    ffa_unit2_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv, blv);
+                    ffa_unit2_asm<XR, UNITLEN>(accA, accB, accB16, accP, xrow4, tapv, alv, blv);
                 else
-                    ffa_unit_asm<XR, UNITLEN>(accA, accB, accB16, accP, (unsigned)reinterpret_cast<uintptr_t>(xrow - 4), tapv, alv);
+                    ffa_unit_asm<XR, UNITLEN>(accA, accB, accB16, accP, xrow4, tapv, alv);
+                (void)hd; (void)Lseg; (void)halo;
             } else {
+                const int row_out = 64 * wv + lane + halo;   // window row holding the lane's outputs
+                const int pos = G.mo0 + 32 * row_out;
+                int sl = (int)((float)pos * A.invK);         // chunk slot of that row (float estimate, corrected)
+                int m_in = pos - sl * A.K;                   // offset of the row inside its chunk
+                if (m_in < 0) { m_in += A.K; sl -= 1; }
+                if (m_in >= A.K) { m_in -= A.K; sl += 1; }
+                const f32x4 *xrow = xs4 + row_out;
 #pragma unroll 1
                 for (int rp = 0; rp <= halo; ++rp) {             // input rows rho' = 0..halo above/at the lane's output row
                     float al;
