@@ -8,9 +8,19 @@
 #pragma once
 #include "bas_internal.h"
 
-// Floats per phase plane of the packed table: [1 front guard = last sample][L samples][3 back guards =
-// first three samples], so a lane can read up to 4 consecutive taps and "one sample earlier" unconditionally.
+// Floats per phase plane of the packed table: [1 front guard = last sample][L samples][the L samples AGAIN][3 back guards =
+// first three samples]: a lane reads its 4 consecutive taps at (tap + circular offset) without a wrap test - round 4; rounds
+// 1-3 kept one copy and wrapped in the evaluator: three vector instructions per read set, 16 of a chunk IR's ~75 in the
+// stagers of the fused kernels, whose vector instructions come out of the filter waves' issue slots - and
+// "one sample earlier" unconditionally.  3.1 MB for the 187 x 8 x 128 table: still inside an XCD's 4 MB L2.
+#ifndef BAS_PLANE_DOUBLE
+#define BAS_PLANE_DOUBLE 1
+#endif
+#if BAS_PLANE_DOUBLE
+#define BAS_PLANE(L) (2 * (L) + 4)
+#else
 #define BAS_PLANE(L) ((L) + 4)
+#endif
 
 // A set's five reads need j - ph0 <= U for every j <= 4: upsampling factors below 4 use bas_interp2d_f32's plain kernel.
 #define BAS_PLAN_MIN_U 4
@@ -36,6 +46,9 @@ struct FzHalf {
 };
 
 __device__ __forceinline__ unsigned fz_wrap(unsigned m4, unsigned o4, unsigned L4) {
+#if BAS_PLANE_DOUBLE
+    return m4 + o4;                                            // (the plane holds its samples twice: m + o < 2 L needs no wrap)
+#endif
     const unsigned idx = m4 + o4;                              // 4 (m + o): m < L, o < L
     const unsigned wr = idx - L4;
     return idx < wr ? idx : wr;                                // idx >= 4 L ? idx - 4 L : idx

@@ -38,11 +38,12 @@ def test_library_is_the_hip_one():
 
 def test_table_pack_layout(dev_tables):
     h, d = dev_tables[("consistent", 128)]
-    packed = d.packed.cpu().numpy().reshape(2, 187, 8, 132)     # [ear][dir][phase][guard + 128 + 3 guards]
+    packed = d.packed.cpu().numpy().reshape(2, 187, 8, 260)     # [ear][dir][phase][guard + 128 + 128 again + 3 guards]
     want = np.stack([h.irs_left, h.irs_right]).astype(np.float32).reshape(2, 187, 128, 8).transpose(0, 1, 3, 2)
     assert np.array_equal(packed[..., 1:129], want)
     assert np.array_equal(packed[..., 0], want[..., -1])        # circular predecessor of sample 0
-    assert np.array_equal(packed[..., 129:], want[..., :3])     # circular successors of the last sample
+    assert np.array_equal(packed[..., 129:257], want)           # the samples again: tap + circular offset never wraps (round 4)
+    assert np.array_equal(packed[..., 257:], want[..., :3])     # circular successors of the last sample
 
 
 def test_delay_signal_float_golden():

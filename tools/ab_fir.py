@@ -50,9 +50,13 @@ handles = [(_hip.use_library(p if os.path.isabs(p) else os.path.join(os.getcwd()
 res = {name: ([], []) for _, name in handles}
 ref = None
 worst = {}
+tbls = {}                                                      # (the packed table's layout belongs to the build: one per library)
 for rnd in range(args.rounds + 1):
     for ctx, name in handles:
         with ctx:
+            if name not in tbls:
+                tbls[name] = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left, host.irs_right)
+            tbl = tbls[name]
             evs = [(mk(), mk()) for _ in range(args.reps)]
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for r in range(args.reps):
