@@ -8,13 +8,14 @@
 #pragma once
 #include "bas_internal.h"
 
-// Floats per phase plane of the packed table: [1 front guard = last sample][L samples][the L samples AGAIN][3 back guards =
-// first three samples]: a lane reads its 4 consecutive taps at (tap + circular offset) without a wrap test - round 4; rounds
-// 1-3 kept one copy and wrapped in the evaluator: three vector instructions per read set, 16 of a chunk IR's ~75 in the
-// stagers of the fused kernels, whose vector instructions come out of the filter waves' issue slots - and
-// "one sample earlier" unconditionally.  3.1 MB for the 187 x 8 x 128 table: still inside an XCD's 4 MB L2.
+// Floats per phase plane of the packed table: [1 front guard = last sample][L samples][3 back guards =
+// first three samples], so a lane can read up to 4 consecutive taps and "one sample earlier" unconditionally.
+// BAS_PLANE_DOUBLE = 1 (round 4, measured, not shipped): [guard][L samples][the L samples AGAIN][3 guards] - a lane then reads
+// at (tap + circular offset) without the wrap test, three vector instructions per read set less in the stagers (16 of a chunk
+// IR's ~75).  Bit-identical; FIR kernel -0.2 .. -1.1 % in the A/B, 0 in the next collection, and 14 MB more table traffic per
+// launch from the 3.1 MB table's L2 misses (profiles/r04_ab_double_planes.txt): not worth its bytes.
 #ifndef BAS_PLANE_DOUBLE
-#define BAS_PLANE_DOUBLE 1
+#define BAS_PLANE_DOUBLE 0
 #endif
 #if BAS_PLANE_DOUBLE
 #define BAS_PLANE(L) (2 * (L) + 4)

@@ -52,14 +52,14 @@ const char *bas_last_error(void);
  * (apply_hrtf.py:23-46): irs_left/irs_right truncated to M = samples_to_keep*U
  * columns (:43-44).  Re-lays the row-major table
  *     irs   [2 ears][ndir][M]            (ear 0 = left)
- * as phase planes that hold their samples TWICE, with guard floats at both ends of every plane
- *     packed[2 ears][ndir][U][2 L + 4],  packed[e][p][i % U][1 + i / U] = packed[e][p][i % U][1 + L + i / U] = irs[e][p][i],
- *     packed[e][p][ph][0] = sample L-1 of the plane, packed[e][p][ph][2L+1 .. 2L+3] = samples 0..2
+ * as phase planes with guard floats at both ends of every plane
+ *     packed[2 ears][ndir][U][L + 4],  packed[e][p][i % U][1 + i / U] = irs[e][p][i],
+ *     packed[e][p][ph][0] = sample L-1 of the plane, packed[e][p][ph][L+1 .. L+3] = samples 0..2
  * (circular neighbours), L = M / U, so that the stride-U reads of a fractional
  * shift followed by decimation (apply_hrtf.py:156-165) are contiguous across
- * lanes and neither "one sample earlier", "the next three taps" nor "tap + circular offset" need a wrap test.
- * bas_table_packed_floats() gives the size of `packed` in floats (0 for invalid shapes); the layout belongs to the
- * library build that packed it. */
+ * lanes and neither "one sample earlier" nor "the next three taps" need a wrap test.  bas_table_packed_floats() gives
+ * the size of `packed` in floats (0 for invalid shapes); the layout belongs to the library build that packed it
+ * (a build with -DBAS_PLANE_DOUBLE=1 keeps every plane's samples twice). */
 size_t bas_table_packed_floats(int ndir, int M, int U);
 int bas_table_pack_f32(const float *irs, int ndir, int M, int U, float *packed,
                        bas_stream_t stream);
