@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void bas_render_fq_kernel(
             }
             if (A.direct) {                                  // uniform
                 const long n0 = t * TILE + 32 * lane0;       // this lane's first output
-                const float lmax = fz_store_row_direct(acc, y, A.T_out, n0, A.accumulate, false);
+                const float lmax = fz_store_row_direct(acc, y, A.T_out, n0, A.accumulate);
                 if (A.tail_mode) {
                     const unsigned b = fz_wave_max_bits(lmax);
                     wmax_bits = b > wmax_bits ? b : wmax_bits;
