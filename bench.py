@@ -86,6 +86,11 @@ def parse():
                          "auto: on whenever the step ends in a collective (N > 1 or --force-pg), where a rank's share is "
                          "short and launch gaps count; off at N = 1, where the FIR kernel is timed with HIP events inside "
                          "the timed steps (events cannot be read back from a graph replay)")
+    ap.add_argument("--overlap-plans", choices=["on", "off"], default="off",
+                    help="A/B: compute the read plans of step i+1 on a second stream beside the FIR of step i (they depend on "
+                         "the trajectories alone; a rank's share leaves CUs free).  Measured SLOWER for every share (27..256 "
+                         "sources: +5..+15 us per step, profiles/r04_ab_overlap_plans.txt): the two cross-stream event waits "
+                         "cost more than the ~9 us launch they hide.  Off: the step is the plain sequence on one stream")
     ap.add_argument("--force-pg", action="store_true",
                     help="with --gpus 1: still create a real RCCL communicator (backend nccl, world_size 1) and run the "
                          "N > 1 code path - async gather to rank 0, fixed-order sum, overlapped steps, device-side "
@@ -447,13 +452,19 @@ class Scene:
                        else lib.bas_render_kernel_name(n_src, in_length, k, s, l).decode())
         self.host_u = host_u
 
-    def render_into(self, y_buf, events, normalize="none"):
+    def render_into(self, y_buf, events, normalize="none", plans=None):
         """a3 -> plans -> (chunk IRs +) FIR + mix + peak [+ the peak rule in the last kernel's tail], all on the
-        current stream.  Returns the peak tensor (max|y| before the rule)."""
+        current stream.  Returns the peak tensor (max|y| before the rule).  plans = a buffer plan_into() has filled
+        (on another stream, ordered before this call by the caller): only the FIR half is launched."""
         bas, a = self.bas, self.args
         return bas.apply_hrtf.render_angles_device(self.x, a.chunk, a.subchunk, self.tbl, self.elev, self.azim,
                                                    normalize=normalize, out=y_buf, events=events, ws=self.ws,
-                                                   ws_plans=self.ws_i, fused=self.fused, params=(self.idx, self.w))[1]
+                                                   ws_plans=self.ws_i if plans is None else plans, fused=self.fused,
+                                                   params=(self.idx, self.w), plans_ready=plans is not None)[1]
+
+    def plan_into(self, plans):
+        """The first launch of the step alone (angles -> a3 -> read plans), on the current stream."""
+        self.bas.apply_hrtf.plan_angles_device(self.tbl, self.elev, self.azim, plans)
 
 
 def self_check(sc, y_dev, peak_dev, n_windows=2):
@@ -505,12 +516,30 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
     # in eager steps of its own right after the timed region (same process, same clocks)
     ev = HipEvents(args.steps) if with_events else None
 
+    # --overlap-plans on (A/B only - it lost, see the option's help): the plans of step i+1 (one launch, ~9 us, latency-bound) are computed on a second stream beside the
+    # FIR of step i - a rank's share of a multi-GPU scene leaves CUs free (247 workgroups at 32 sources), and the plans
+    # depend on the trajectories alone.  Plan buffers are double-buffered; two events per buffer order plan -> FIR -> the
+    # next plan into the same buffer.  Every timed step still contains one plan launch and one FIR (the first step's
+    # plans come from the warm-up, the last step computes the plans of a step that is not rendered).
+    pipe = args.overlap_plans == "on" and sc.fused_used
+    if pipe:
+        side = torch.cuda.Stream(dev)
+        plan_bufs = [sc.ws_i, torch.empty_like(sc.ws_i)]
+        plan_done = [torch.cuda.Event(), torch.cuda.Event()]
+        fir_done = [torch.cuda.Event(), torch.cuda.Event()]
+        pcount = [0]
+        with torch.cuda.stream(side):                         # prime: the plans of the first step
+            sc.plan_into(plan_bufs[0])
+            plan_done[0].record(side)
+        info["overlap_plans"] = ("the read plans of step i+1 (bas_interp2d_plan_angles_f32) are computed on a second "
+                                 "stream beside the FIR of step i; double-buffered, event-ordered")
+
     def mix_on_root(parts_buf):                             # fixed-order sum + max|y| + peak rule: ONE launch
         _hip.call("bas_mix_finish_f32", _hip.ptr(parts_buf), world, 2 * t_out, 2 * t_out, _hip.ptr(sc.y_final),
                   _hip.ptr(sc.peak), 1, _hip.ptr(sc.ws_mix), sc.ws_mix.numel(), _hip.current_stream(dev))
 
-    def render_single(y_buf, events=None):                  # the whole N = 1 step: render with the peak rule in its tail
-        sc.last_peak = sc.render_into(y_buf, events, normalize="mix")
+    def render_single(y_buf, events=None, plans=None):      # the whole N = 1 step: render with the peak rule in its tail
+        sc.last_peak = sc.render_into(y_buf, events, normalize="mix", plans=plans)
 
     # N > 1: the gather of step i travels (RCCL stream, xGMI) while step i+1 renders; y and the root's receive
     # buffer are double-buffered, the root sums step i right after it has launched step i+1's gather.  Every
@@ -527,10 +556,30 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
     # ---- the render part of a step as ONE hipGraph (per output buffer): a3 -> plans -> FIR -> reduce [-> peak rule]
     graphs = {}
 
+    def fir_half(b, p, events=None):
+        """The step behind its plans (pipelined form): FIR + reduce [+ rule] into ys[b] from plan_bufs[p]."""
+        if use_graph and events is None and (b, p) in graphs:
+            graphs[(b, p)].replay()
+        elif collective:
+            sc.render_into(ys[b], events, plans=plan_bufs[p])
+        else:
+            render_single(ys[b], events, plans=plan_bufs[p])
+
     def render(b, events=None):
         """Render this rank's sources into ys[b] (collective path: un-normalised partial mix; N = 1: with the peak
         rule), replaying the captured graph when there is one and no events are asked for."""
-        if use_graph and events is None and b in graphs:
+        if pipe:
+            p = pcount[0] & 1
+            pcount[0] += 1
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(plan_done[p])                     # (computed beside the previous step's FIR)
+            fir_half(b, p, events)
+            fir_done[p].record(main)
+            side.wait_event(fir_done[p ^ 1])                  # the FIR that read the other buffer (previous step) is over
+            with torch.cuda.stream(side):
+                sc.plan_into(plan_bufs[p ^ 1])
+                plan_done[p ^ 1].record(side)
+        elif use_graph and events is None and b in graphs:
             graphs[b].replay()
         elif collective:
             sc.render_into(ys[b], events)
@@ -541,14 +590,16 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
         for b in range(len(ys)):
             render(b)                                         # eager first: code objects, workspaces
         torch.cuda.synchronize(dev)
-        for b in range(len(ys)):
+        for key in ([(b, p) for b in range(len(ys)) for p in (0, 1)] if pipe else range(len(ys))):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                if collective:
-                    sc.render_into(ys[b], None)
+                if pipe:
+                    fir_half(key[0], key[1])                  # (not in `graphs` yet: plain launches, recorded)
+                elif collective:
+                    sc.render_into(ys[key], None)
                 else:
-                    render_single(ys[b], None)
-            graphs[b] = g
+                    render_single(ys[key], None)
+            graphs[key] = g
 
     def launch_gather(b, async_op):
         if backend == "nccl":

@@ -262,7 +262,8 @@ def render_device(x, chunksize, subchunksize, H, tbl_L, normalize="mix", out=Non
 
 @_hip.on_device_of("x")
 def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix", out=None, events=None,
-                         ws=None, ws_plans=None, fused=None, angles=None, n_queries=None, want_peak=True, check=False):
+                         ws=None, ws_plans=None, fused=None, angles=None, n_queries=None, want_peak=True, check=False,
+                         plans_ready=False):
     """interpolate_2d + render for precomputed parameters: x [n_src, T_in] device float32,
     idx int32 [n_src*(n_chunks+1), 4], w float64 [.., 3] on the device.  Uses the fused kernel
     (chunk IRs evaluated inside the FIR kernel, never stored) when the sizes allow it, else
@@ -270,7 +271,9 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     normalize="mix": the peak rule (apply_hrtf.py:462-464) inside the render call (the tail of its last kernel: no launch
     of its own).  want_peak=False with normalize="none": max|y| is not computed at all (returns peak None; streams track
     their own running peak).  ws: a workspace from _hip.new_workspace (zeroed control block).  check=True: ask the
-    library for device-side errors afterwards (synchronises the stream: for callers that copy the result to the host anyway)."""
+    library for device-side errors afterwards (synchronises the stream: for callers that copy the result to the host anyway).
+    plans_ready=True: ws_plans already holds this scene's read plans (plan_angles_device on another stream, ordered before
+    this call by the caller): only the fused FIR is launched; needs n_queries and a shape the fused kernels serve."""
     import torch
     tbl = as_device_table(tbl)
     dev = x.device
@@ -282,6 +285,8 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
         fused = bool(lib.bas_render_fused_supported(n_src, t_in, chunksize, subchunksize, tbl.L)) and \
             tbl.upsampling >= 4 and x.data_ptr() % 16 == 0 and x.stride(0) % 4 == 0
     n_q = idx.shape[0] if idx is not None else n_queries
+    if plans_ready and not fused:
+        raise ValueError("plans_ready: this shape is not served by the fused kernels (they are the ones that read plans)")
     if not fused:
         if idx is None:                                       # (angles given, shape not served by the fused kernel)
             idx, w = sphere.interpolation_params_device(angles[0], angles[1], branch=angles[2])
@@ -299,7 +304,10 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     if ws is None or ws.numel() < wb:
         ws = _hip.new_workspace(wb, dev)
     stream = _hip.current_stream(dev)
-    if angles is None:
+    if plans_ready:
+        if ws_plans.numel() < pb:
+            raise ValueError("plans_ready: ws_plans is smaller than bas_interp2d_workspace_bytes(n_queries)")
+    elif angles is None:
         _hip.call("bas_interp2d_plan_f32", _hip.ptr(tbl.diffs), _hip.ptr(idx), _hip.ptr(w), n_q, tbl.ndir, tbl.L,
                   tbl.upsampling, _hip.ptr(ws_plans), ws_plans.numel(), stream)
     else:                                                     # small batch: a3 + plans in one launch
@@ -319,12 +327,36 @@ def render_params_device(x, chunksize, subchunksize, tbl, idx, w, normalize="mix
     return y, peak
 
 
+def plan_angles_device(tbl, elev, azim, ws_plans, branch="f64"):
+    """The first launch of render_angles_device alone, on the current stream: trajectory angles (float64 device tensors,
+    one per source and chunk boundary) -> a3 -> the fused kernels' read plans in ws_plans (uint8 device tensor of at least
+    bas_interp2d_workspace_bytes(elev.numel()) bytes).  For callers that render a SEQUENCE of scenes and let the plans of
+    the next one be computed beside the FIR of the current one (bench.py --overlap-plans; a rank's share of a multi-GPU
+    scene leaves CUs free): render_params_device(..., plans_ready=True) is the other half."""
+    import torch
+    tbl = as_device_table(tbl)
+    if not (elev.is_cuda and azim.is_cuda and elev.dtype == torch.float64 and azim.dtype == torch.float64
+            and elev.is_contiguous() and azim.is_contiguous() and elev.numel() == azim.numel()):
+        raise ValueError("elev/azim must be contiguous float64 device tensors of equal size")
+    if branch not in sphere.BRANCHES:
+        raise ValueError("branch must be 'f64' or 'pyfloat'")
+    n_q, dev = elev.numel(), elev.device
+    if ws_plans.numel() < _hip.lib().bas_interp2d_workspace_bytes(n_q):
+        raise ValueError("ws_plans is smaller than bas_interp2d_workspace_bytes(n_queries)")
+    ring_elev, ring_start, ring_count = sphere._ring_args()
+    _hip.call("bas_interp2d_plan_angles_f32", _hip.ptr(tbl.diffs), _hip.ptr(elev), _hip.ptr(azim), n_q, ring_elev,
+              ring_start, ring_count, _hip.ptr(sphere.device_nodes(dev)), sphere.BRANCHES[branch], tbl.ndir, tbl.L,
+              tbl.upsampling, _hip.ptr(ws_plans), ws_plans.numel(), _hip.current_stream(dev))
+    return ws_plans
+
+
 MERGED_A3_MAX_QUERIES = 1 << 30     # a3 rides inside the plan kernel (one launch less; see bas.h) for every batch size since round 4:
                                     # the angle arithmetic is done once per query by half of a block's waves and handed over through LDS
 
 
 def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize="mix", out=None, events=None,
-                         ws=None, ws_plans=None, fused=None, params=None, branch="f64", want_peak=True, check=False):
+                         ws=None, ws_plans=None, fused=None, params=None, branch="f64", want_peak=True, check=False,
+                         plans_ready=False):
     """The whole device side of make_signal_move_2d for trajectories that live on the GPU: x [n_src, T_in] device
     float32 (T_in % K == 0), elev / azim float64 device tensors [n_src, T_in/K + 1] (radians at t = 0, K, .., T_in).
     bas_traj_params_f64 (a3 + the elevation bracket), then render_params_device (read plans + fused FIR where the
@@ -346,7 +378,9 @@ def render_angles_device(x, chunksize, subchunksize, tbl, elev, azim, normalize=
             raise ValueError("branch must be 'f64' or 'pyfloat'")
         return render_params_device(x, chunksize, subchunksize, tbl, None, None, normalize, out=out, events=events, ws=ws,
                                     ws_plans=ws_plans, fused=fused, angles=(elev, azim, branch), n_queries=elev.numel(),
-                                    want_peak=want_peak, check=check)
+                                    want_peak=want_peak, check=check, plans_ready=plans_ready)
+    if plans_ready:
+        raise ValueError("plans_ready needs contiguous angle tensors (the merged a3 + plan launch)")
     idx, w = sphere.interpolation_params_device(elev, azim, out=params, branch=branch)
     return render_params_device(x, chunksize, subchunksize, tbl, idx.reshape(-1, 4), w.reshape(-1, 3), normalize,
                                 out=out, events=events, ws=ws, ws_plans=ws_plans, fused=fused, want_peak=want_peak, check=check)

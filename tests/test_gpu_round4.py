@@ -309,3 +309,29 @@ def test_shipped_library_fuses_small_subchunks_for_big_scenes(s):
             want += orc.render_window(sigs[i, m0:m1].astype(np.float64), m0, k, s, ir_of, l, n0, n1)
         worst = max(worst, float(np.abs(got[n0:n1].T - want).max()) / scale)
     assert worst <= REL, worst
+
+
+def test_plans_on_another_stream_then_the_fir_half():
+    """plan_angles_device on a second stream + render_angles_device(plans_ready=True) behind an event (what
+    bench.py --overlap-plans on does per step) == the one-stream render, bit for bit; the errors of the two halves."""
+    import torch
+    h, sigs, elev, azim, in_length = _scene(128, 12, 120000, 512, 0.3)
+    d, x, _, _ = _device_inputs(h, sigs, elev, azim, in_length)
+    e, z = torch.from_numpy(elev).cuda(), torch.from_numpy(azim).cuda()
+    want, peak = bas.apply_hrtf.render_angles_device(x, 512, 32, d, e, z, normalize="mix")
+    plans = torch.empty((bas._hip.lib().bas_interp2d_workspace_bytes(e.numel()),), dtype=torch.uint8, device="cuda")
+    side, done = torch.cuda.Stream(), torch.cuda.Event()
+    with torch.cuda.stream(side):
+        bas.apply_hrtf.plan_angles_device(d, e, z, plans)
+        done.record(side)
+    torch.cuda.current_stream().wait_event(done)
+    got, peak2 = bas.apply_hrtf.render_angles_device(x, 512, 32, d, e, z, normalize="mix", ws_plans=plans, plans_ready=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(peak, peak2)
+    with pytest.raises(ValueError, match="smaller than"):
+        bas.apply_hrtf.plan_angles_device(d, e, z, plans[:64])
+    with pytest.raises(ValueError, match="float64"):
+        bas.apply_hrtf.plan_angles_device(d, e.float(), z.float(), plans)
+    with pytest.raises(ValueError, match="plans_ready"):       # K = 96: stored chunk IRs, nothing reads plans
+        bas.apply_hrtf.render_angles_device(x[:, :96 * 100], 96, 32, d, e[:, :101].contiguous(), z[:, :101].contiguous(),
+                                            ws_plans=plans, plans_ready=True)
