@@ -794,10 +794,13 @@ extern "C" size_t bas_render_fused_workspace_bytes(int n_src, long T_in, int K, 
 
 // phases: 1 = the FIR kernel (slab parts, or y itself for scenes whose tiles are each finished by one workgroup),
 // 2 = the slab reduce (+ max|y| + peak rule), 3 = both.  One implementation behind bas_render_mix_fused_f32,
-// bas_render_mix_fused_profiled_f32, bas_render_fused_fir_f32 and bas_render_fused_reduce_f32.
+// bas_render_mix_fused_profiled_f32, bas_render_fused_fir_f32, bas_render_fused_reduce_f32 and bas_render_stream_block_f32.
+// carry != null (a stream block: no peak, no rule): the carried state is moved - and the running peak taken over the emitted
+// samples - by the reduce kernel behind its sums where there is one, by the epilogue kernel where the FIR kernel writes y itself.
 static int fused_impl(const char *who, int phases, const float *x, long x_stride, const float *packed, const void *plans,
                       int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y, int accumulate, float *peak,
-                      int normalize, void *ws, size_t ws_bytes, bas_stream_t stream, void *ev_begin, void *ev_end) {
+                      int normalize, void *ws, size_t ws_bytes, bas_stream_t stream, void *ev_begin, void *ev_end,
+                      const BasCarry *carry = nullptr) {
     BAS_REQUIRE(y, BAS_E_NULL, "%s: y is null", who);
     BAS_REQUIRE(n_src >= 0 && T_in >= 0 && K > 0 && S > 0 && L > 0 && ndir > 0, BAS_E_SHAPE,
                 "%s: need n_src>=0, T_in>=0, K,S,L,ndir>0 (n_src=%d T_in=%ld K=%d S=%d L=%d)", who, n_src, T_in, K, S, L);
@@ -904,9 +907,13 @@ static int fused_impl(const char *who, int phases, const float *x, long x_stride
     if (!A.direct) {                                         // direct output: y and the peak are complete
         int skipped = 1;
         int rc = bas_launch_slab_reduce(slab, p.tile, n_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
-                                        peak_bits, want_peak ? &T : nullptr, &skipped, st, who);
+                                        peak_bits, want_peak ? &T : nullptr, &skipped, carry, st, who);
         if (rc) return rc;
         rule_done = !skipped && T.normalize != 0;
+    } else if (carry) {
+        return bas_stream_epilogue_f32(carry->x, carry->x_stride, carry->n_src, carry->halo, carry->B, carry->elev, carry->azim,
+                                       carry->ang_stride, carry->nh, carry->nb, carry->last, y, T_out,
+                                       reinterpret_cast<float *>(carry->running_peak), stream);
     }
     if (normalize && !rule_done) return bas_scale_by_peak_f32(y, 2 * T_out, peak_dev, stream);
     return 0;
@@ -940,4 +947,44 @@ extern "C" int bas_render_fused_reduce_f32(const float *x, long x_stride, const 
                                            float *peak, int normalize, void *ws, size_t ws_bytes, bas_stream_t stream) {
     return fused_impl("bas_render_fused_reduce_f32", 2, x, x_stride, packed, plans, n_src, T_in, K, S, L, U, ndir, y,
                       accumulate, peak, normalize, ws, ws_bytes, stream, nullptr, nullptr);
+}
+
+// One block of a stream (stream.py; bas.h "streaming"): the fused render of the window [halo | block] into y - no peak of
+// the window, no rule: a stream's samples are handed out before its peak is known - and the carried state of
+// bas_stream_epilogue_f32, which rides in the reduce kernel where the scene has one (a launch less per block: 4.4 of the
+// 30 us of a 256 x 512 real-time block).  x is written (its halo), T_in = halo + B.
+static int stream_block_impl(const char *who, float *x, long x_stride, const float *packed, const void *plans, int n_src,
+                             long T_in, int K, int S, int L, int U, int ndir, float *y, void *ws, size_t ws_bytes, int halo,
+                             double *elev, double *azim, long ang_stride, int nh, int nb, double *last, float *running_peak,
+                             bas_stream_t stream, void *ev_begin, void *ev_end) {
+    const long B = T_in - halo;
+    BAS_REQUIRE(n_src > 0 && halo >= 0 && B > 0 && nh >= 0 && nb >= 2, BAS_E_SHAPE,
+                "%s: need n_src>0, halo>=0, T_in>halo, nh>=0, nb>=2 (n_src=%d halo=%d T_in=%ld nh=%d nb=%d)", who, n_src, halo,
+                T_in, nh, nb);
+    BAS_REQUIRE(ang_stride >= nh + nb, BAS_E_SHAPE, "%s: ang_stride shorter than nh + nb", who);
+    BAS_REQUIRE(x && elev && azim && last, BAS_E_NULL, "%s: null pointer", who);
+    BasCarry C;
+    C.x = x; C.x_stride = x_stride; C.n_src = n_src; C.halo = halo; C.B = B;
+    C.elev = elev; C.azim = azim; C.ang_stride = ang_stride; C.nh = nh; C.nb = nb; C.last = last;
+    C.running_peak = reinterpret_cast<unsigned int *>(running_peak);
+    return fused_impl(who, 3, x, x_stride, packed, plans, n_src, T_in, K, S, L, U, ndir, y, 0, nullptr, 0, ws, ws_bytes, stream,
+                      ev_begin, ev_end, &C);
+}
+
+extern "C" int bas_render_stream_block_f32(float *x, long x_stride, const float *packed, const void *plans, int n_src,
+                                           long T_in, int K, int S, int L, int U, int ndir, float *y, void *ws,
+                                           size_t ws_bytes, int halo, double *elev, double *azim, long ang_stride, int nh,
+                                           int nb, double *last, float *running_peak, bas_stream_t stream) {
+    return stream_block_impl("bas_render_stream_block_f32", x, x_stride, packed, plans, n_src, T_in, K, S, L, U, ndir, y, ws,
+                             ws_bytes, halo, elev, azim, ang_stride, nh, nb, last, running_peak, stream, nullptr, nullptr);
+}
+
+extern "C" int bas_render_stream_block_profiled_f32(float *x, long x_stride, const float *packed, const void *plans,
+                                                    int n_src, long T_in, int K, int S, int L, int U, int ndir, float *y,
+                                                    void *ws, size_t ws_bytes, int halo, double *elev, double *azim,
+                                                    long ang_stride, int nh, int nb, double *last, float *running_peak,
+                                                    bas_stream_t stream, void *ev_begin, void *ev_end) {
+    return stream_block_impl("bas_render_stream_block_profiled_f32", x, x_stride, packed, plans, n_src, T_in, K, S, L, U, ndir,
+                             y, ws, ws_bytes, halo, elev, azim, ang_stride, nh, nb, last, running_peak, stream, ev_begin,
+                             ev_end);
 }

@@ -22,9 +22,22 @@ int bas_grid_for(long items, int cap);
 int bas_device_cus();                                  // CU count of the current device, cached
 hipError_t bas_allow_full_lds(const void *fn);         // dynamic-LDS limit of a kernel raised once per device
 struct BasTail;                                        // bas_tail.h
+// Carried state of a stream block (bas_stream.hip; bas.h "streaming"): what bas_stream_epilogue_f32 moves after a window's
+// render.  The slab reduce kernels take one and do that work behind their own (x == null: nothing) - a launch less per block.
+struct BasCarry {
+    float *x;                   // [n_src] rows [halo | block]: the last halo samples move to the front
+    long x_stride;
+    int n_src, halo;
+    long B;
+    double *elev, *azim;        // [n_src] rows of nh + nb angles: the halo's boundaries move to the front
+    long ang_stride;
+    int nh, nb;
+    double *last;               // [2][n_src]: the angles at the block's end
+    unsigned int *running_peak; // max|y| bits over the samples emitted so far (may be null)
+};
 int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per_wg, int parts_per_wg, int n_wg,
                            long T_out, float *y, int accumulate, unsigned int *peak_bits, const BasTail *tail,
-                           int *tail_skipped, hipStream_t st, const char *what);
+                           int *tail_skipped, const BasCarry *carry, hipStream_t st, const char *what);
 // Workspaces start with a head the library owns: the 2048-byte control block (zero between calls) and BAS_TAIL_MAX_WG
 // per-workgroup maxima (bas_tail.h); the slabs follow.
 #define BAS_TAIL_MAX_WG 4096
@@ -96,5 +109,32 @@ __device__ __forceinline__ void bas_block_peak_max(float lmax, unsigned int *pea
     if (threadIdx.x == 0) {
         const unsigned int mine = __float_as_uint(fmaxf(fmaxf(wave_max[0], wave_max[1]), fmaxf(wave_max[2], wave_max[3])));
         if (mine > __hip_atomic_load(peak_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(peak_bits, mine);
+    }
+}
+
+// The moves of a stream block's carried state (everything but the running peak), by `nthreads` threads of which this is `tid`.
+__device__ __forceinline__ void bas_carry_moves(const BasCarry &C, long tid, long nthreads) {
+    float *x = C.x;
+    const int halo = C.halo, n_src = C.n_src, nh = C.nh, nb = C.nb;
+    const long B = C.B;
+    // ---- input halo: x[s][0 .. halo) = x[s][B .. B + halo)
+    if (B >= halo) {                                         // source and destination ranges are disjoint
+        for (long i = tid; i < (long)n_src * halo; i += nthreads) {
+            const long s = i / halo, j = i - s * halo;
+            x[s * C.x_stride + j] = x[s * C.x_stride + B + j];
+        }
+    } else {                                                 // block shorter than the halo (L - 1 > B): the ranges overlap,
+        for (long s = tid; s < n_src; s += nthreads)         // one thread moves a row front to back (reads run ahead of writes)
+            for (int j = 0; j < halo; ++j) x[s * C.x_stride + j] = x[s * C.x_stride + B + j];
+    }
+    // ---- angles: boundaries t0+B-halo .. t0+B-K move to the front; the boundary at t0+B is remembered for finish()
+    for (long s = tid; s < n_src; s += nthreads) {
+        double *e = C.elev + s * C.ang_stride, *a = C.azim + s * C.ang_stride;
+        C.last[s] = e[nh + nb - 1];
+        C.last[n_src + s] = a[nh + nb - 1];
+        for (int j = 0; j < nh; ++j) {                       // ascending: source index nb - 1 + j > j
+            e[j] = e[nb - 1 + j];
+            a[j] = a[nb - 1 + j];
+        }
     }
 }

@@ -802,9 +802,12 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__res
                                                                 int n_src, int units_per_wg,
                                                                 int parts_per_wg, int n_wg, long T_out,
                                                                 float *__restrict__ y, int accumulate,
-                                                                unsigned int *peak_bits, BasTail T) {
+                                                                unsigned int *peak_bits, BasTail T, BasCarry C) {
     float lmax = 0.f;
     const long n4 = (T_out + 3) / 4;
+    // C.x != null (a stream block, never together with a tail): the maximum is taken over the samples the block emits and
+    // goes into the stream's running peak; the carried state is moved behind the sums (bas_carry_moves)
+    const long plo = C.x ? C.halo : 0, phi = C.x ? C.halo + C.B : T_out;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256L) {
         const long n = i * 4;
         // (tiles * n_src = units_total < 2^31 is checked by the launcher: 32-bit divisions suffice)
@@ -848,12 +851,15 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_kernel(const float *__res
                     y[n + j] = a;
                     y[T_out + n + j] = b;
                 }
-                lmax = fmaxf(lmax, fmaxf(fabsf(a), fabsf(b)));
+                if (n + j >= plo && n + j < phi) lmax = fmaxf(lmax, fmaxf(fabsf(a), fabsf(b)));
             }
         }
     }
     if (T.ctl) {
         bas_tail<256>(T, lmax);
+    } else if (C.x) {
+        if (C.running_peak) bas_block_peak_max(lmax, C.running_peak);
+        bas_carry_moves(C, blockIdx.x * 256L + threadIdx.x, (long)gridDim.x * 256L);
     } else if (peak_bits) {
         bas_block_peak_max(lmax, peak_bits);
     }
@@ -867,8 +873,9 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_wide_kernel(const float *
                                                                      int n_src, int units_per_wg,
                                                                      int parts_per_wg, int n_wg, long T_out,
                                                                      float *__restrict__ y, int accumulate,
-                                                                     unsigned int *peak_bits, BasTail T) {
+                                                                     unsigned int *peak_bits, BasTail T, BasCarry C) {
     __shared__ f32x4 part_sum[4][64];
+    const long plo = C.x ? C.halo : 0, phi = C.x ? C.halo + C.B : T_out;     // (a stream block: see bas_slab_reduce_kernel)
     const int col = threadIdx.x & 3, pl = threadIdx.x >> 2;
     const long cols_per_ear = (T_out + 3) / 4;
     const long blocks_per_ear = (cols_per_ear + 3) / 4;
@@ -908,12 +915,15 @@ __global__ __launch_bounds__(256) void bas_slab_reduce_wide_kernel(const float *
                     bas_store1_sc1(ye + n + j, a);
                 else
                     ye[n + j] = a;
-                lmax = fmaxf(lmax, fabsf(a));
+                if (n + j >= plo && n + j < phi) lmax = fmaxf(lmax, fabsf(a));
             }
         }
     }
     if (T.ctl) {
         bas_tail<256>(T, lmax);
+    } else if (C.x) {
+        if (C.running_peak) bas_block_peak_max(lmax, C.running_peak);
+        bas_carry_moves(C, blockIdx.x * 256L + threadIdx.x, (long)gridDim.x * 256L);
     } else if (peak_bits) {
         bas_block_peak_max(lmax, peak_bits);
     }
@@ -1044,7 +1054,13 @@ hipError_t bas_allow_full_lds(const void *fn) {
 // form (returns 1 in *tail_skipped: the caller launches the scale kernel itself).
 int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per_wg, int parts_per_wg, int n_wg,
                            long T_out, float *y, int accumulate, unsigned int *peak_bits, const BasTail *tail,
-                           int *tail_skipped, hipStream_t st, const char *what) {
+                           int *tail_skipped, const BasCarry *carry, hipStream_t st, const char *what) {
+    BasCarry C = {};
+    if (carry) {                                             // a stream block: its own maximum, no tail (see the kernels)
+        C = *carry;
+        tail = nullptr;
+        peak_bits = nullptr;
+    }
     const int parts = (n_src + units_per_wg - 1) / units_per_wg + 1;       // workgroups that can share one tile
     BasTail T = {};
     if (tail_skipped) *tail_skipped = 1;
@@ -1056,7 +1072,7 @@ int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per
             if (tail_skipped) *tail_skipped = 0;
         }
         hipLaunchKernelGGL(bas_slab_reduce_wide_kernel, dim3((unsigned)(2 * blocks_per_ear)), dim3(256), 0, st, slab, tile,
-                           n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits, T);
+                           n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits, T, C);
         return bas_check_launch(what);
     }
     const int grid = bas_grid_for((T_out + 3) / 4, 2048);
@@ -1066,7 +1082,7 @@ int bas_launch_slab_reduce(const float *slab, int tile, int n_src, int units_per
         if (tail_skipped) *tail_skipped = 0;
     }
     hipLaunchKernelGGL(bas_slab_reduce_kernel, dim3(grid), dim3(256), 0, st, slab, tile,
-                       n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits, T);
+                       n_src, units_per_wg, parts_per_wg, n_wg, T_out, y, accumulate, peak_bits, T, C);
     return bas_check_launch(what);
 }
 
@@ -1268,7 +1284,7 @@ static int render_mix_impl(const float *x, long x_stride, const float *H, int n_
     int rc = bas_check_launch(p.kind == KIND_HD ? "bas_render_mix_f32(hd)" : "bas_render_mix_f32(rows32)");
     if (rc) return rc;
     return bas_launch_slab_reduce(A.slab, p.tile, live_src, p.units_per_wg, p.parts_per_wg, p.n_wg, T_out, y, accumulate,
-                                  peak_bits, nullptr, nullptr, st, "bas_render_mix_f32(reduce)");
+                                  peak_bits, nullptr, nullptr, nullptr, st, "bas_render_mix_f32(reduce)");
 }
 
 extern "C" int bas_render_mix_f32(const float *x, long x_stride, const float *H, int n_src, long T_in,

@@ -22,26 +22,10 @@ __global__ __launch_bounds__(256) void bas_stream_epilogue_kernel(
         lmax = fmaxf(lmax, fabsf(y[e * y_stride + halo + (i - e * B)]));
     }
     if (peak_bits) bas_block_peak_max(lmax, peak_bits);
-    // ---- input halo: x[s][0 .. halo) = x[s][B .. B + halo)
-    if (B >= halo) {                                         // source and destination ranges are disjoint
-        for (long i = tid; i < (long)n_src * halo; i += nthreads) {
-            const long s = i / halo, j = i - s * halo;
-            x[s * x_stride + j] = x[s * x_stride + B + j];
-        }
-    } else {                                                 // block shorter than the halo (L - 1 > B): the ranges overlap,
-        for (long s = tid; s < n_src; s += nthreads)         // one thread moves a row front to back (reads run ahead of writes)
-            for (int j = 0; j < halo; ++j) x[s * x_stride + j] = x[s * x_stride + B + j];
-    }
-    // ---- angles: boundaries t0+B-halo .. t0+B-K move to the front; the boundary at t0+B is remembered for finish()
-    for (long s = tid; s < n_src; s += nthreads) {
-        double *e = elev + s * ang_stride, *a = azim + s * ang_stride;
-        last[s] = e[nh + nb - 1];
-        last[n_src + s] = a[nh + nb - 1];
-        for (int j = 0; j < nh; ++j) {                       // ascending: source index nb - 1 + j > j
-            e[j] = e[nb - 1 + j];
-            a[j] = a[nb - 1 + j];
-        }
-    }
+    BasCarry C;
+    C.x = x; C.x_stride = x_stride; C.n_src = n_src; C.halo = halo; C.B = B;
+    C.elev = elev; C.azim = azim; C.ang_stride = ang_stride; C.nh = nh; C.nb = nb; C.last = last; C.running_peak = peak_bits;
+    bas_carry_moves(C, tid, nthreads);                       // (the input halo, the halo's angles, the block's last angles)
 }
 
 extern "C" int bas_stream_epilogue_f32(float *x, long x_stride, int n_src, int halo, long B, double *elev, double *azim,

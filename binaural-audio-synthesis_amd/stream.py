@@ -15,10 +15,11 @@ and tracks the running peak (`peak`), so a caller can scale afterwards exactly a
 reference would.  Long streams (BASELINE config 5: 1 h at 48 kHz, 1024 sources) never
 materialise more than one block of inputs, chunk IRs and outputs.
 
-One block = five launches on persistent buffers: angles -> parameters (bas_traj_params_f64),
-read plans, the fused chunk-IR / FIR / mix kernel, its slab reduce, and
-bas_stream_epilogue_f32 (running peak over the emitted samples + every carry copy).  With
-graph=True those are replayed as ONE hipGraph launch.  `prepare(B)` lays the buffers out and
+One block = three launches on persistent buffers (bas_render_stream_block_f32): angles ->
+read plans, the fused chunk-IR / FIR / mix kernel, and its slab reduce, which also takes the
+running peak over the emitted samples and makes every carry copy (scenes whose FIR kernel
+writes y itself, and shapes the fused kernels do not serve, end in bas_stream_epilogue_f32
+instead).  With graph=True those are replayed as ONE hipGraph launch.  `prepare(B)` lays the buffers out and
 captures the graph BEFORE streaming starts (capture synchronises the device and must not
 race with allocations of other threads: keep it out of the real-time phase); without it the
 first block of a size runs as plain launches and the second one captures.
@@ -30,10 +31,12 @@ tiles of 2048 samples anyway - a 512-sample block with a 512-sample halo is ONE 
 source, exactly as it would be with a 128-sample halo.
 """
 from . import _hip
-from .apply_hrtf import as_device_table, render_angles_device
+from .apply_hrtf import as_device_table, plan_angles_device, render_angles_device
 
 
 class StreamRenderer:
+    one_call = True      # bas_render_stream_block_f32 where the fused kernels serve the block (False: render + epilogue launch; A/B, tests)
+
     def __init__(self, tbl, n_src, chunksize, subchunksize, graph=True, copy_out=True):
         """graph: replay each block as one captured hipGraph (captured by prepare(), else on the second block of a
         size).  copy_out: process() returns a fresh tensor (True) or a view of the renderer's output buffer that
@@ -122,12 +125,30 @@ class StreamRenderer:
         B, nb, nh, halo = self._B, self._nb, self.nh, self.halo
         dev = self.tbl.device
         x = self._xbuf[:, :halo + B]
-        # a3, read plans, chunk IRs + FIR + mix (or the stored-IR path for other sizes)
+        tbl, n = self.tbl, self.n_src
+        lib = _hip.lib()
+        with _hip.on_device(dev):
+            one_call = self.one_call and bool(lib.bas_render_fused_supported(n, halo + B, self.K, self.S, tbl.L)) and tbl.upsampling >= 4 \
+                and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+        if one_call:
+            # read plans (a3 inside), then ONE call: chunk IRs + FIR + mix, and behind the sums of its reduce kernel the
+            # running peak over the emitted samples + the carry of the last `halo` inputs and of the angles at their chunk
+            # boundaries (t0+B-halo .. t0+B-K) + the angles at t0+B for finish()
+            plan_angles_device(tbl, self._elev_all, self._azim_all, self._ws_plans)
+            args = (_hip.ptr(self._xbuf), self._xbuf.stride(0), _hip.ptr(tbl.packed), _hip.ptr(self._ws_plans), n, halo + B,
+                    self.K, self.S, tbl.L, tbl.upsampling, tbl.ndir, _hip.ptr(self._y), _hip.ptr(self._ws), self._ws.numel(),
+                    halo, _hip.ptr(self._elev_all), _hip.ptr(self._azim_all), self._elev_all.stride(0), nh, nb,
+                    _hip.ptr(self._last), _hip.ptr(self._peak_dev), _hip.current_stream(dev))
+            with _hip.on_device(dev):
+                if self._events is None:
+                    _hip.call("bas_render_stream_block_f32", *args)
+                else:
+                    _hip.call("bas_render_stream_block_profiled_f32", *args, self._events[0], self._events[1])
+            return
+        # other shapes: a3, read plans, chunk IRs + FIR + mix (or the stored-IR path), then the epilogue launch
         render_angles_device(x, self.K, self.S, self.tbl, self._elev_all, self._azim_all, normalize="none",
                              out=self._y, ws=self._ws, ws_plans=self._ws_plans, params=(self._idx, self._w),
                              events=self._events, want_peak=False)   # (the epilogue tracks the peak of the EMITTED samples)
-        # running peak over the emitted samples + carry of the last `halo` inputs and of the angles at their
-        # chunk boundaries (t0+B-halo .. t0+B-K) + the angles at t0+B for finish(): one launch
         with _hip.on_device(dev):
             _hip.call("bas_stream_epilogue_f32", _hip.ptr(self._xbuf), self._xbuf.stride(0), self.n_src, halo, B,
                       _hip.ptr(self._elev_all), _hip.ptr(self._azim_all), self._elev_all.stride(0), nh, nb,

@@ -93,7 +93,10 @@ int bas_ring_interp_f32(const float *packed, const double *diffs, const int32_t 
  *   elev, azim [n] f64 (device); idx [n][4] int32, w [n][3] f64 (device)
  *   ring_elev[10] f64, ring_start[10], ring_count[10] int32: HOST arrays (the ten rings:
  *   deg2rad(-45..90), first direction index, number of azimuths); node_az [187] f32
- *   DEVICE array of the table's node azimuths (sphere.py:318 float32 values). */
+ *   DEVICE array of the table's node azimuths (sphere.py:318 float32 values), ascending
+ *   inside every ring with the ring's first node at azimuth 0, as sphere.py:124-319 lists
+ *   them: the search for "the last node <= azim" (sphere.py:103) starts from azim's
+ *   position on an evenly spaced ring and walks to the exact node. */
 int bas_traj_params_f64(const double *elev, const double *azim, long n, const double *ring_elev,
                         const int32_t *ring_start, const int32_t *ring_count, const float *node_az,
                         int32_t *idx, double *w, bas_stream_t stream);
@@ -297,6 +300,31 @@ int bas_stream_epilogue_f32(float *x, long x_stride, int n_src, int halo, long B
                             double *azim, long ang_stride, int nh, int nb, double *last,
                             const float *y, long y_stride, float *running_peak,
                             bas_stream_t stream);
+
+/* One block of a stream in one call (behind read plans of the window's chunk boundaries,
+ * bas_interp2d_plan_angles_f32 over elev/azim [n_src][nh+nb]): the fused render of the
+ * window x[s][0 .. T_in), T_in = halo + B, into y [2][T_in+L-1] - overwritten, no peak of
+ * the window, no peak rule: a stream's samples leave before apply_hrtf.py:462-464 could
+ * know its peak - followed by everything bas_stream_epilogue_f32 does (same arguments,
+ * y_stride = T_in+L-1).  Where the scene's FIR kernel leaves slabs, the carried state and
+ * the running peak ride in the reduce kernel (no launch of their own: 4.4 us of a
+ * 256 x 512 real-time block's 30); where it writes y itself, the epilogue kernel is
+ * launched.  Same results either way.  Sizes must be served by the fused kernels
+ * (bas_render_fused_supported(n_src, T_in, K, S, L)); workspace as for
+ * bas_render_mix_fused_f32.  x is WRITTEN (its first halo samples).
+ * _profiled: HIP events around the FIR kernel (bench.py). */
+int bas_render_stream_block_f32(float *x, long x_stride, const float *packed, const void *plans,
+                                int n_src, long T_in, int K, int S, int L, int U, int ndir,
+                                float *y, void *ws, size_t ws_bytes, int halo, double *elev,
+                                double *azim, long ang_stride, int nh, int nb, double *last,
+                                float *running_peak, bas_stream_t stream);
+int bas_render_stream_block_profiled_f32(float *x, long x_stride, const float *packed,
+                                         const void *plans, int n_src, long T_in, int K, int S,
+                                         int L, int U, int ndir, float *y, void *ws,
+                                         size_t ws_bytes, int halo, double *elev, double *azim,
+                                         long ang_stride, int nh, int nb, double *last,
+                                         float *running_peak, bas_stream_t stream,
+                                         void *ev_begin, void *ev_end);
 
 #ifdef __cplusplus
 }

@@ -335,3 +335,70 @@ def test_plans_on_another_stream_then_the_fir_half():
     with pytest.raises(ValueError, match="plans_ready"):       # K = 96: stored chunk IRs, nothing reads plans
         bas.apply_hrtf.render_angles_device(x[:, :96 * 100], 96, 32, d, e[:, :101].contiguous(), z[:, :101].contiguous(),
                                             ws_plans=plans, plans_ready=True)
+
+
+@pytest.mark.parametrize("n_src,k,blocks", [
+    (256, 512, (512, 512, 1024, 512)),        # many sources on short blocks: the wide reduce kernel carries the state
+    (40, 512, (16384, 8192, 16384)),          # the plain reduce kernel
+    (1, 512, (4096, 2048)),                   # one source: the FIR kernel writes y itself, the epilogue kernel is launched
+    (5, 128, (128, 256, 128)),                # chunk size the fused kernels do not serve: render + epilogue as before
+])
+def test_stream_block_in_one_call_equals_render_plus_epilogue(n_src, k, blocks):
+    """bas_render_stream_block_f32 (the carried state and the running peak in the reduce kernel's tail) against the
+    two-call form (render, then bas_stream_epilogue_f32): the same emitted samples, bit for bit, block after block (every
+    block depends on the state the one before carried over), the same running peak and the same tail from finish(); and
+    against the whole-signal render."""
+    import torch
+    l, s = 128, 32
+    n = sum(blocks)
+    h = bas.synth.make_table("consistent", 0).truncated(l)
+    d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    sigs = np.stack([bas.synth.integer_noise(900 + i, n, 0.5 / max(n_src, 1) ** 0.5) for i in range(n_src)])
+    t = np.arange(0, n + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        elev[i], azim[i] = bas.synth.trajectory(("spiral", "circle_askew", "passing")[i % 3], period_s=0.05 + 0.003 * i,
+                                                length_s=n / 44100, turns=2.0, phase=0.3 * i)(t)
+    outs = {}
+    for one_call in (True, False):
+        st = bas.StreamRenderer(d, n_src, k, s, graph=False)
+        st.one_call = one_call
+        got, pos = [], 0
+        for b in blocks:
+            c0, c1 = pos // k, (pos + b) // k
+            got.append(st.process(sigs[:, pos:pos + b], elev[:, c0:c1 + 1], azim[:, c0:c1 + 1]))
+            pos += b
+        got.append(st.finish())
+        outs[one_call] = (torch.cat(got, dim=0), st.peak)
+    assert torch.equal(outs[True][0], outs[False][0])
+    assert outs[True][1] == outs[False][1]
+    whole = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none")
+    assert rel_err(outs[True][0].cpu().numpy(), whole.cpu().numpy()) <= 1e-6
+    assert abs(outs[True][1] - float(whole.abs().max())) <= 1e-6 * outs[True][1]
+
+
+def test_stream_block_under_graph_replay_carries_state():
+    """The one-call block captured into the stream's hipGraph (prepare()): replays concatenate to the whole-signal render."""
+    import torch
+    n_src, k, s, l, b, nblk = 64, 512, 32, 128, 1024, 6
+    n = b * nblk
+    h = bas.synth.make_table("consistent", 0).truncated(l)
+    d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    sigs = np.stack([bas.synth.integer_noise(950 + i, n, 0.05) for i in range(n_src)])
+    t = np.arange(0, n + 1, k, dtype=np.float64)
+    elev = np.empty((n_src, t.size))
+    azim = np.empty((n_src, t.size))
+    for i in range(n_src):
+        elev[i], azim[i] = bas.synth.trajectory("spiral", period_s=0.05 + 0.003 * i, length_s=n / 44100, turns=2.0, phase=0.3 * i)(t)
+    st = bas.StreamRenderer(d, n_src, k, s, graph=True)
+    st.prepare(b)
+    assert st._graph is not None
+    got = []
+    for i in range(nblk):
+        c0, c1 = i * b // k, (i + 1) * b // k
+        got.append(st.process(sigs[:, i * b:(i + 1) * b], elev[:, c0:c1 + 1], azim[:, c0:c1 + 1]))
+    got.append(st.finish())
+    whole = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none")
+    assert rel_err(torch.cat(got, dim=0).cpu().numpy(), whole.cpu().numpy()) <= 1e-6
+    assert abs(st.peak - float(whole.abs().max())) <= 1e-6 * st.peak

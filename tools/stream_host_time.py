@@ -16,6 +16,10 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 k, s, l, n_blocks = 512, 32, 128, 400
 host = bas.synth.make_table("consistent", 0).truncated(l)
 tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left, host.irs_right)
+# third argument "two": the round-3 form of a block (render, then the epilogue launch) instead of bas_render_stream_block_f32
+if len(sys.argv) > 3 and sys.argv[3] == "two":
+    bas.StreamRenderer.one_call = False
+form = "one call (carry in the reduce kernel)" if bas.StreamRenderer.one_call else "render + epilogue launch"
 for graph in (True, False):
     st = bas.StreamRenderer(tbl, n_src, k, s, graph=graph, copy_out=False)
     xin = st.input_view(B)
@@ -35,6 +39,6 @@ for graph in (True, False):
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t_all) / n_blocks * 1e6
     host_us.sort()
-    print(f"{n_src} sources x {B}-sample blocks, {'hipGraph replay' if graph else 'plain launches'}: "
+    print(f"{n_src} sources x {B}-sample blocks, {form}, {'hipGraph replay' if graph else 'plain launches'}: "
           f"host {np.median(host_us):.1f} us/call (p10 {host_us[len(host_us) // 10]:.1f}, p90 {host_us[9 * len(host_us) // 10]:.1f}), "
           f"wall {wall:.1f} us/block = {B / 44100 * 1e6 / wall:.0f} x real time")
