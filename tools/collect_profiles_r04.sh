@@ -69,7 +69,10 @@ if has stream; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o bench -- python3 bench.py --no-traffic --mode stream --sources 1024 --fs 48000 --steps 40 --warmup 3 > /dev/null 2>> $O/stream.err
   $B --mode stream --sources 1024 --fs 48000 --steps 100 --warmup 3 --force-pg > $O/stream_forcepg.json 2>> $O/stream.err
   python3 tools/stream_host_time.py 256 512 2>/dev/null > $O/stream_host_time.txt
+  python3 tools/stream_host_time.py 256 512 two 2>/dev/null >> $O/stream_host_time.txt      # A/B: render + epilogue launch
   python3 tools/stream_host_time.py 256 32768 2>/dev/null >> $O/stream_host_time.txt
+  python3 tools/stream_host_time.py 256 32768 two 2>/dev/null >> $O/stream_host_time.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rt -o rt -- python3 tools/stream_host_time.py 256 512 > /dev/null 2>> $O/stream.err
   echo "[stream] done"
 fi
 

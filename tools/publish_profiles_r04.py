@@ -44,7 +44,7 @@ for rel, name in [("bench_default.json", "bench.json"), ("bench_300.json", "benc
                   ("single_source_latency.txt", "single_source_latency.txt"),
                   ("stream_hour.json", "stream_hour.json"), ("stream_hour_regen.json", "stream_hour_regen.json"),
                   ("prof_stream/bench_kernel_stats.csv", "kernel_stats_stream.csv"), ("stream_forcepg.json", "stream_forcepg_nccl_world1.json"),
-                  ("stream_host_time.txt", "stream_host_time.txt"), ("prof_share32/bench_kernel_stats.csv", "kernel_stats_32sources.csv"),
+                  ("stream_host_time.txt", "stream_host_time.txt"), ("prof_rt/rt_kernel_stats.csv", "kernel_stats_realtime_block.csv"), ("prof_share32/bench_kernel_stats.csv", "kernel_stats_32sources.csv"),
                   ("forcepg_timeline.txt", "forcepg_timeline.txt"), ("ab_rolling_x.txt", "ab_rolling_x.txt"),
                   ("ab_sensitivity.txt", "ab_sensitivity.txt"), ("ubench_unit_block.txt", "ubench_unit_block.txt"),
                   ("stamps_fs_256.txt", "stamps_fs_256sources.txt"), ("bench_2ranks_one_device.json", "bench_2ranks_one_device.json"),
