@@ -64,6 +64,8 @@ SIGNATURES = {
                                     _c_void_p]),
     "bas_stream_epilogue_f32": (_c_int, [_c_void_p, _c_long, _c_int, _c_int, _c_long, _c_void_p, _c_void_p, _c_long,
                                          _c_int, _c_int, _c_void_p, _c_void_p, _c_long, _c_void_p, _c_void_p]),
+    "bas_resample_up_f64": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p]),
+    "bas_delaydiffs_f64": (_c_int, [_c_void_p, _c_int, _c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),
     "bas_render_stream_block_f32": (_c_int, [_c_void_p, _c_long, _c_void_p, _c_void_p, _c_int, _c_long, _c_int, _c_int,
                                              _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_size_t, _c_int, _c_void_p,
                                              _c_void_p, _c_long, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p]),

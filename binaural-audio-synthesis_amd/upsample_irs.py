@@ -17,8 +17,11 @@ half-length 10 max(p, q)).  What IS tested (tests/test_upsample_irs.py): known a
 parameters), antisymmetry and zero diagonal of the delay matrices, exact known answers for shifted
 impulses, and that the written file loads through load_irs_and_delaydiffs's indexing.
 
-This is an offline, run-once precompute on the host (17 391 pairs x 2 ears of 512-tap correlations, batched
-per row of the pair matrix through FFTs); it is not part of the render path and has no GPU kernel.
+Two forms.  `upsample_irs` is the host restatement (numpy; 17 391 pairs x 2 ears of 512-tap correlations, batched per
+row of the pair matrix through FFTs; ~10 s on one core) - the definition the tests hold the device form against.
+`upsample_irs_device` runs the same two steps as HIP kernels (csrc/bas_table.hip: bas_delaydiffs_f64, bas_resample_up_f64;
+float64, direct sums; the whole 187 x 512-tap table in tens of milliseconds) and needs the GPU library like every other
+product path - no fallback.  Neither is part of the render path.
 """
 import numpy as np
 
@@ -160,6 +163,50 @@ def upsample_irs(hrirs_left, hrirs_right, upsampling=8, progress=None):
         raise ValueError("upsample_irs: resampled length is not n_taps * upsampling")
     return {"upsampling": float(upsampling), "diffs_left": dl, "diffs_right": dr,
             "irs_left": irs_left, "irs_right": irs_right}
+
+
+_DD_ERRORS = {1: "delaydifference: cross-correlation peak at the edge of its support",           # (upsample_irs.m:70)
+              2: "parabolic_interpolation: the middle point is not the (first) maximum",       # (:92-93)
+              3: "parabolic_interpolation: three collinear points"}                             # (:98)
+
+
+def upsample_irs_device(hrirs_left, hrirs_right, upsampling=8, device=None):
+    """upsample_irs on the GPU: the same dict (numpy float64 arrays), computed by bas_delaydiffs_f64 (every pair's
+    cross-correlation, x U resampling, first maximum, parabola: upsample_irs.m:15-32, :58-101) and bas_resample_up_f64
+    (:37-44).  The resampling filter is designed on the host (octave_resample_filter) and handed to the kernels.  The
+    reference's preconditions raise ValueError naming the first pair that failed, as the host form does.  Raises if the
+    HIP library or a GPU is missing (no host fallback)."""
+    import torch
+    from . import _hip
+    hl = np.ascontiguousarray(hrirs_left, dtype=np.float64)
+    hr = np.ascontiguousarray(hrirs_right, dtype=np.float64)
+    if hl.shape != hr.shape or hl.ndim != 2:
+        raise ValueError("upsample_irs: need two (n_dir, n_taps) arrays of equal shape")
+    p = int(upsampling)
+    if p < 1 or p != upsampling:
+        raise ValueError("upsample_irs: the upsampling factor must be a positive integer")
+    n_dir, n_taps = hl.shape
+    dev = torch.device(device if device is not None else "cuda")
+    _hip.require_gpu(dev)
+    h, lh = octave_resample_filter(p, 1)
+    with _hip.on_device(dev):
+        stream = _hip.current_stream(dev)
+        h_d = torch.from_numpy(h).to(dev)
+        out = {"upsampling": float(p)}
+        for ear, x in (("left", hl), ("right", hr)):
+            x_d = torch.from_numpy(x).to(dev)
+            diffs = torch.empty((n_dir, n_dir), dtype=torch.float64, device=dev)
+            status = torch.empty((4,), dtype=torch.int32, device=dev)
+            irs = torch.empty((n_dir, n_taps * p), dtype=torch.float64, device=dev)
+            _hip.call("bas_delaydiffs_f64", _hip.ptr(x_d), n_dir, n_taps, _hip.ptr(h_d), lh, p, _hip.ptr(diffs),
+                      _hip.ptr(status), stream)
+            _hip.call("bas_resample_up_f64", _hip.ptr(x_d), n_dir, n_taps, _hip.ptr(h_d), lh, p, _hip.ptr(irs), stream)
+            st = status.cpu().tolist()                       # (synchronises)
+            if st[0] != 0:
+                raise ValueError(f"{_DD_ERRORS.get(st[0], 'delaydifference failed')} ({ear} ear, directions {st[1]} and {st[2]})")
+            out["diffs_" + ear] = diffs.cpu().numpy()
+            out["irs_" + ear] = irs.cpu().numpy()
+    return out
 
 
 def save(path, table):

@@ -326,6 +326,27 @@ int bas_render_stream_block_profiled_f32(float *x, long x_stride, const float *p
                                          float *running_peak, bas_stream_t stream,
                                          void *ev_begin, void *ev_end);
 
+/* ---- table builder: the heavy parts of upsample_irs.m ---------
+ * PARITY UNPINNED (no Octave, no IRCAM data in the build: upsample_irs.py's header).  All
+ * arrays float64 on the device; h = the 2 Lh + 1 taps of the resampling filter Octave's
+ * resample(x, p, 1) designs (upsample_irs.py: octave_resample_filter), made on the host.
+ *
+ * bas_resample_up_f64: y[r][j] = sum_k h[j + Lh - p k] x[r][k], j < lx p: `rows` signals
+ *   of lx samples resampled by p (upsample_irs.m:37-44: the 2 x 187 HRIRs).
+ * bas_delaydiffs_f64: diffs [n_dir][n_dir] (overwritten) = the antisymmetric matrix of
+ *   delay differences (upsample_irs.m:15-32, :58-101): for every pair i < j the
+ *   cross-correlation of irs[i], irs[j] ([n_dir][n_taps]), resampled by p, its FIRST
+ *   maximum refined by a parabola; diffs[i][j] = peak / p - (n_taps - 1), diffs[j][i] =
+ *   -diffs[i][j], zero diagonal.  status: 4 ints on the device (overwritten): status[0] = 0,
+ *   or the reference's failed precondition for the first pair that hit one - 1: peak at
+ *   the edge of the correlation's support (:70), 2: the middle point is not the first
+ *   maximum (:92-93), 3: three collinear points (:98) - with the pair in status[1], [2]
+ *   (that pair's entries stay zero).  One ear per call. */
+int bas_resample_up_f64(const double *x, int rows, int lx, const double *h, int Lh, int p,
+                        double *y, bas_stream_t stream);
+int bas_delaydiffs_f64(const double *irs, int n_dir, int n_taps, const double *h, int Lh, int p,
+                       double *diffs, int *status, bas_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

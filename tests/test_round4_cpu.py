@@ -81,6 +81,18 @@ def test_argument_errors_of_the_round4_entry_points():
         assert err.value.code == -2 and "subchunksize does not divide chunksize evenly" in str(err.value)
 
 
+def test_argument_errors_of_the_table_builder_entry_points():
+    lib = bas._hip.lib()
+    buf = (ctypes.c_char * 4096)()
+    a = ctypes.addressof(buf)
+    assert lib.bas_resample_up_f64(None, 1, 8, a, 3, 2, a, None) == -1                  # null x
+    assert lib.bas_resample_up_f64(a, 0, 8, a, 3, 2, a, None) == -2                     # no rows
+    assert lib.bas_resample_up_f64(a, 1, 8000, a, 300, 8, a, None) == -2 and b"LDS" in lib.bas_last_error()
+    assert lib.bas_delaydiffs_f64(a, 3, 16, a, 3, 2, a, None, None) == -1               # null status
+    assert lib.bas_delaydiffs_f64(a, 70000, 16, a, 3, 2, a, a, None) == -2 and b"65535" in lib.bas_last_error()
+    assert lib.bas_delaydiffs_f64(a, 3, 16, a, 0, 2, a, a, None) == -2                  # Lh = 0
+
+
 def test_vectorized_trajectory_that_cannot_broadcast_falls_back(monkeypatch):
     """make_signal_move_2d(vectorized=True) with a function that raises on an array argument (math.sin) must take the
     scalar path instead of failing; checked on the host logic alone by stopping at the first device call."""
