@@ -213,3 +213,40 @@ def save(path, table):
     """Write the struct the way `save -6` does for the reference (upsample_irs.m:53): MATLAB v5."""
     import scipy.io
     scipy.io.savemat(path, {"irs_and_delaydiffs": table}, format="5")
+
+
+def load_ircam_hrirs(path):
+    """The two `content_m` matrices (n_dir, n_taps) of an IRCAM LISTEN file such as IRC_1032_C_HRIR.mat - the structs
+    `l_eq_hrir_S` / `r_eq_hrir_S` that upsample_irs.m:1, :25-26 reads (the raw files hold `l_hrir_S` / `r_hrir_S`, :2)."""
+    import scipy.io
+    m = scipy.io.loadmat(path)
+    for lname, rname in (("l_eq_hrir_S", "r_eq_hrir_S"), ("l_hrir_S", "r_hrir_S")):
+        if lname in m and rname in m:
+            return (np.asarray(m[lname][0][0]["content_m"], dtype=np.float64),
+                    np.asarray(m[rname][0][0]["content_m"], dtype=np.float64))
+    raise ValueError(f"{path}: no l_eq_hrir_S / r_eq_hrir_S (or l_hrir_S / r_hrir_S) structs")
+
+
+def build_table(hrir_mat, out_mat="irs_and_delaydiffs.mat", upsampling=8, on_host=False, device=None):
+    """What running upsample_irs.m does: HRIR database in, `irs_and_delaydiffs` struct out (:53 saves it under that name;
+    the reference's loader expects the file renamed, apply_hrtf.py:23).  On the GPU unless on_host (the numpy definition)."""
+    hl, hr = load_ircam_hrirs(hrir_mat)
+    table = upsample_irs(hl, hr, upsampling) if on_host else upsample_irs_device(hl, hr, upsampling, device=device)
+    save(out_mat, table)
+    return table
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="Build the HRIR table load_irs_and_delaydiffs reads (the reference's upsample_irs.m).")
+    ap.add_argument("hrir_mat", help="IRCAM LISTEN HRIR file, e.g. IRC_1032_C_HRIR.mat")
+    ap.add_argument("out_mat", nargs="?", default="irs_and_delaydiffs.mat")
+    ap.add_argument("--upsampling", type=int, default=8)
+    ap.add_argument("--host", action="store_true", help="the numpy definition instead of the HIP kernels (~10 s)")
+    a = ap.parse_args(argv)
+    t = build_table(a.hrir_mat, a.out_mat, a.upsampling, on_host=a.host)
+    print(f"{a.out_mat}: {t['irs_left'].shape[0]} directions x {t['irs_left'].shape[1]} samples, upsampling {int(t['upsampling'])}")
+
+
+if __name__ == "__main__":
+    main()

@@ -102,3 +102,17 @@ def test_full_size_table_on_the_device_and_through_the_loader(tmp_path):
     assert tbl.upsampling == 8 and tuple(tbl.irs_left.shape) == (187, 1024)
     ir = bas.interpolate_2d(tbl, 0.1, 0.7)
     assert tuple(ir.shape) == (2, 128) and bool(np.isfinite(np.asarray(ir.cpu() if hasattr(ir, "cpu") else ir)).all())
+
+
+def test_build_table_on_the_device_from_an_ircam_shaped_file(tmp_path):
+    import scipy.io
+    rng = np.random.default_rng(4)
+    hl = _noisy_pulses(rng, 9, 80, 30.0, 5.0)
+    hr = _noisy_pulses(rng, 9, 80, 30.0, 5.0)
+    src, dst = str(tmp_path / "IRC_test_C_HRIR.mat"), str(tmp_path / "irs_and_delaydiffs.mat")
+    scipy.io.savemat(src, {"l_eq_hrir_S": {"content_m": hl}, "r_eq_hrir_S": {"content_m": hr}}, format="5")
+    up.main([src, dst])
+    rec = scipy.io.loadmat(dst)["irs_and_delaydiffs"][0][0]
+    want = up.upsample_irs(hl, hr, 8)
+    assert np.abs(rec["diffs_left"] - want["diffs_left"]).max() <= 1e-9
+    assert np.abs(rec["irs_right"] - want["irs_right"]).max() <= 1e-12

@@ -135,3 +135,25 @@ def test_full_size_table_builds_quickly():
     assert time.perf_counter() - t0 < 240
     assert t["irs_left"].shape == (187, 4096) and t["diffs_right"].shape == (187, 187)
     assert np.allclose(t["diffs_left"], pos[0][None, :] - pos[0][:, None], atol=5e-3)
+
+
+def test_build_table_from_an_ircam_shaped_file(tmp_path):
+    """build_table / main: a file with the structs upsample_irs.m:1, :25-26 reads (l_eq_hrir_S.content_m, r_eq_hrir_S.content_m)
+    in, the struct apply_hrtf.py:38-44 indexes out (host form here: no GPU)."""
+    rng = np.random.default_rng(2)
+    n_dir, n_taps = 5, 48
+    hl = np.stack([_pulse(n_taps, 18 + rng.uniform(-3, 3)) for _ in range(n_dir)])
+    hr = np.stack([_pulse(n_taps, 18 + rng.uniform(-3, 3)) for _ in range(n_dir)])
+    src, dst = str(tmp_path / "IRC_test_C_HRIR.mat"), str(tmp_path / "out.mat")
+    scipy.io.savemat(src, {"l_eq_hrir_S": {"content_m": hl, "sampling_hz": 44100.0},
+                           "r_eq_hrir_S": {"content_m": hr, "sampling_hz": 44100.0}}, format="5")
+    gl, gr = up.load_ircam_hrirs(src)
+    assert np.array_equal(gl, hl) and np.array_equal(gr, hr)
+    up.main([src, dst, "--upsampling", "4", "--host"])
+    rec = scipy.io.loadmat(dst)["irs_and_delaydiffs"][0][0]
+    want = up.upsample_irs(hl, hr, 4)
+    assert int(rec["upsampling"][0][0]) == 4
+    assert np.array_equal(rec["irs_left"], want["irs_left"]) and np.array_equal(rec["diffs_right"], want["diffs_right"])
+    with pytest.raises(ValueError):
+        scipy.io.savemat(src, {"something_else": hl})
+        up.load_ircam_hrirs(src)
