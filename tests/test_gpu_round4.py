@@ -402,3 +402,34 @@ def test_stream_block_under_graph_replay_carries_state():
     whole = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none")
     assert rel_err(torch.cat(got, dim=0).cpu().numpy(), whole.cpu().numpy()) <= 1e-6
     assert abs(st.peak - float(whole.abs().max())) <= 1e-6 * st.peak
+
+
+@pytest.mark.parametrize("branch", ["f64", "pyfloat"])
+def test_ring_search_at_and_around_every_node(branch):
+    """a3's search for the last node <= azim (sphere.py:103) starts from the azimuth's position on an evenly spaced ring and
+    walks to the exact node: azimuths AT every node of every ring (the float32 table value as a double), one float64 and one
+    float32 step to either side of it, just below 2 pi, negative and beyond 2 pi - device == host, bit for bit, both
+    branches of the comparison (float64 azimuth against the float32 node / float32 against float32)."""
+    import torch
+    sp = bas.sphere
+    tab = np.asarray(sp.index_elev_azim)
+    elevs, azims = [], []
+    for ring, (start, count) in enumerate(zip(sp.RING_START, sp.RING_COUNTS)):
+        e_ring = float(tab[start, 1])
+        for e in (e_ring, e_ring - 0.03, e_ring + 0.02):
+            for v in tab[start:start + count, 2]:
+                v64 = float(v)
+                cands = [v64, np.nextafter(v64, -1.0), np.nextafter(v64, 10.0), float(np.nextafter(v, np.float32(-1))),
+                         float(np.nextafter(v, np.float32(10))), v64 + 2 * np.pi, v64 - 2 * np.pi, v64 + 1e-9, v64 - 1e-9]
+                elevs += [e] * len(cands)
+                azims += cands
+            for z in (2 * np.pi, np.nextafter(2 * np.pi, 0.0), float(np.float32(2 * np.pi)), -1e-12, 0.0, -0.0, 4 * np.pi - 1e-9):
+                elevs.append(e)
+                azims.append(z)
+    e = np.array(elevs, dtype=np.float64)
+    z = np.array(azims, dtype=np.float64)
+    idx_h, w_h = sp.interpolation_params_batch(e, z, branch=branch)
+    idx_d, w_d = sp.interpolation_params_device(torch.from_numpy(e).cuda(), torch.from_numpy(z).cuda(), branch=branch)
+    assert np.array_equal(idx_d.cpu().numpy().reshape(idx_h.shape), idx_h)
+    assert np.array_equal(w_d.cpu().numpy().reshape(w_h.shape), w_h)
+    assert e.size > 5000
