@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void bas_resample_up_kernel(const double *__re
 // diffs[i][j] = d, diffs[j][i] = -d (the antisymmetry of :31-32); the diagonal is the caller's (zero).
 __global__ __launch_bounds__(256) void bas_delaydiff_kernel(const double *__restrict__ irs, int n_dir, int n,
                                                               const double *__restrict__ h, int Lh, int p,
-                                                              double *__restrict__ diffs, int *__restrict__ status) {
+                                                              double *__restrict__ diffs,
+                                                              unsigned long long *__restrict__ status) {
     const int j2 = blockIdx.x, i2 = blockIdx.y;
     if (j2 <= i2) return;                                    // (uniform: the lower triangle and the diagonal have no work)
     extern __shared__ double sh[];
@@ -118,11 +119,9 @@ __global__ __launch_bounds__(256) void bas_delaydiff_kernel(const double *__rest
             }
         }
     }
-    if (code) {                                              // the first failing pair is reported (status[0] = 0 on entry)
-        if (atomicCAS(status, 0, code) == 0) {
-            status[1] = i2;
-            status[2] = j2;
-        }
+    if (code) {                                              // the failing pair with the smallest (i, j) is reported, whoever ran first
+        const unsigned long long pair = (unsigned long long)i2 * n_dir + j2;
+        atomicMax(status, ((((unsigned long long)n_dir * n_dir) - pair) << 2) | (unsigned long long)code);
         return;
     }
     diffs[(long)i2 * n_dir + j2] = d;
@@ -149,17 +148,18 @@ extern "C" int bas_resample_up_f64(const double *x, int rows, int lx, const doub
 }
 
 extern "C" int bas_delaydiffs_f64(const double *irs, int n_dir, int n_taps, const double *h, int Lh, int p, double *diffs,
-                                  int *status, bas_stream_t stream) {
+                                  unsigned long long *status, bas_stream_t stream) {
     int rc = table_args("bas_delaydiffs_f64", irs, n_dir, n_taps, h, Lh, p);
     if (rc) return rc;
     BAS_REQUIRE(diffs && status, BAS_E_NULL, "bas_delaydiffs_f64: diffs or status is null");
+    BAS_REQUIRE(reinterpret_cast<uintptr_t>(status) % 8 == 0, BAS_E_ALIGN, "bas_delaydiffs_f64: status must be 8-byte aligned");
     BAS_REQUIRE(n_dir <= 65535, BAS_E_SHAPE, "bas_delaydiffs_f64: more than 65535 directions");
     const size_t lds = sizeof(double) * (size_t)(2 * Lh + 1 + 2 * n_taps + 2 * n_taps - 1);
     BAS_REQUIRE(lds <= 64 * 1024, BAS_E_SHAPE,
                 "bas_delaydiffs_f64: filter, two signals and their correlation (%zu bytes) must fit 64 KB of LDS", lds);
     hipStream_t st = bas_stream(stream);
     hipError_t e = hipMemsetAsync(diffs, 0, sizeof(double) * (size_t)n_dir * n_dir, st);
-    if (e == hipSuccess) e = hipMemsetAsync(status, 0, 4 * sizeof(int), st);
+    if (e == hipSuccess) e = hipMemsetAsync(status, 0, sizeof(unsigned long long), st);
     if (e != hipSuccess) return bas_fail((int)e, "bas_delaydiffs_f64: hipMemsetAsync: %s", hipGetErrorString(e));
     if (n_dir < 2) return 0;
     hipLaunchKernelGGL(bas_delaydiff_kernel, dim3((unsigned)n_dir, (unsigned)n_dir), dim3(256), lds, st, irs, n_dir, n_taps, h,

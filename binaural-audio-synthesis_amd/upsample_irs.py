@@ -196,14 +196,16 @@ def upsample_irs_device(hrirs_left, hrirs_right, upsampling=8, device=None):
         for ear, x in (("left", hl), ("right", hr)):
             x_d = torch.from_numpy(x).to(dev)
             diffs = torch.empty((n_dir, n_dir), dtype=torch.float64, device=dev)
-            status = torch.empty((4,), dtype=torch.int32, device=dev)
+            status = torch.empty((1,), dtype=torch.int64, device=dev)
             irs = torch.empty((n_dir, n_taps * p), dtype=torch.float64, device=dev)
             _hip.call("bas_delaydiffs_f64", _hip.ptr(x_d), n_dir, n_taps, _hip.ptr(h_d), lh, p, _hip.ptr(diffs),
                       _hip.ptr(status), stream)
             _hip.call("bas_resample_up_f64", _hip.ptr(x_d), n_dir, n_taps, _hip.ptr(h_d), lh, p, _hip.ptr(irs), stream)
-            st = status.cpu().tolist()                       # (synchronises)
-            if st[0] != 0:
-                raise ValueError(f"{_DD_ERRORS.get(st[0], 'delaydifference failed')} ({ear} ear, directions {st[1]} and {st[2]})")
+            st = int(status.cpu()[0])                        # (synchronises)
+            if st != 0:                                      # ((n_dir^2 - pair) << 2) | code of the smallest failing pair (bas.h)
+                pair = n_dir * n_dir - (st >> 2)
+                raise ValueError(f"{_DD_ERRORS.get(st & 3, 'delaydifference failed')} ({ear} ear, directions "
+                                 f"{pair // n_dir} and {pair % n_dir})")
             out["diffs_" + ear] = diffs.cpu().numpy()
             out["irs_" + ear] = irs.cpu().numpy()
     return out

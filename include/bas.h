@@ -337,15 +337,16 @@ int bas_render_stream_block_profiled_f32(float *x, long x_stride, const float *p
  *   delay differences (upsample_irs.m:15-32, :58-101): for every pair i < j the
  *   cross-correlation of irs[i], irs[j] ([n_dir][n_taps]), resampled by p, its FIRST
  *   maximum refined by a parabola; diffs[i][j] = peak / p - (n_taps - 1), diffs[j][i] =
- *   -diffs[i][j], zero diagonal.  status: 4 ints on the device (overwritten): status[0] = 0,
- *   or the reference's failed precondition for the first pair that hit one - 1: peak at
- *   the edge of the correlation's support (:70), 2: the middle point is not the first
- *   maximum (:92-93), 3: three collinear points (:98) - with the pair in status[1], [2]
- *   (that pair's entries stay zero).  One ear per call. */
+ *   -diffs[i][j], zero diagonal.  status: ONE 64-bit word on the device (overwritten,
+ *   8-byte aligned): 0, or - where a pair hit one of the reference's preconditions -
+ *   ((n_dir^2 - (i n_dir + j)) << 2) | code for the failing pair with the smallest (i, j)
+ *   (the same one whichever workgroup ran first); code 1: peak at the edge of the
+ *   correlation's support (:70), 2: the middle point is not the first maximum (:92-93),
+ *   3: three collinear points (:98).  Failing pairs' entries stay zero.  One ear per call. */
 int bas_resample_up_f64(const double *x, int rows, int lx, const double *h, int Lh, int p,
                         double *y, bas_stream_t stream);
 int bas_delaydiffs_f64(const double *irs, int n_dir, int n_taps, const double *h, int Lh, int p,
-                       double *diffs, int *status, bas_stream_t stream);
+                       double *diffs, unsigned long long *status, bas_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -88,7 +88,9 @@ def test_argument_errors_of_the_table_builder_entry_points():
     assert lib.bas_resample_up_f64(None, 1, 8, a, 3, 2, a, None) == -1                  # null x
     assert lib.bas_resample_up_f64(a, 0, 8, a, 3, 2, a, None) == -2                     # no rows
     assert lib.bas_resample_up_f64(a, 1, 8000, a, 300, 8, a, None) == -2 and b"LDS" in lib.bas_last_error()
+    a += (-a) % 16
     assert lib.bas_delaydiffs_f64(a, 3, 16, a, 3, 2, a, None, None) == -1               # null status
+    assert lib.bas_delaydiffs_f64(a, 3, 16, a, 3, 2, a, a + 4, None) == -3              # status not 8-byte aligned
     assert lib.bas_delaydiffs_f64(a, 70000, 16, a, 3, 2, a, a, None) == -2 and b"65535" in lib.bas_last_error()
     assert lib.bas_delaydiffs_f64(a, 3, 16, a, 0, 2, a, a, None) == -2                  # Lh = 0
 
