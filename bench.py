@@ -84,8 +84,10 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the render step (a3 -> plans -> FIR -> reduce [-> peak rule]) as ONE captured hipGraph. "
                          "auto: on whenever the step ends in a collective (N > 1 or --force-pg), where a rank's share is "
-                         "short and launch gaps count; off at N = 1, where the FIR kernel is timed with HIP events inside "
-                         "the timed steps (events cannot be read back from a graph replay)")
+                         "short and launch gaps count, and for scenes small enough for the four-wave kernel (a single "
+                         "source: three short launches); off for the headline scene at N = 1, where the FIR kernel is "
+                         "timed with HIP events inside the timed steps (events cannot be read back from a graph replay: "
+                         "under a graph it is timed in eager steps right behind the timed region)")
     ap.add_argument("--overlap-plans", choices=["on", "off"], default="off",
                     help="A/B: compute the read plans of step i+1 on a second stream beside the FIR of step i (they depend on "
                          "the trajectories alone; a rank's share leaves CUs free).  Measured SLOWER for every share (27..256 "
@@ -511,7 +513,9 @@ def run_scene(args, bas, dev, world, rank, backend, scaling, tbl, host_u, with_e
     sc = Scene(args, bas, dev, world, rank, scaling, tbl, host_u)
     t_out = sc.t_out
     info = {}
-    use_graph = args.graph == "on" or (args.graph == "auto" and collective)
+    # auto: graphs where the step is a chain of short launches - the collective path, and scenes small enough for the
+    # four-wave kernel (one source x 10 s: 33 us as plain launches, 28.5 us replayed: three kernels of 25 us together)
+    use_graph = args.graph == "on" or (args.graph == "auto" and (collective or sc.kernel.startswith("bas_render_fq_kernel")))
     # events live inside the timed steps only while those are plain launches; under a graph the FIR kernel is timed
     # in eager steps of its own right after the timed region (same process, same clocks)
     ev = HipEvents(args.steps) if with_events else None
