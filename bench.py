@@ -75,7 +75,10 @@ def parse():
                     help="scene = the contract's benchmark (default); stream = BASELINE config 5 shape: long stream "
                          "rendered block by block with carried state, inputs and trajectories generated on the device")
     ap.add_argument("--fs", type=int, default=FS)
-    ap.add_argument("--block", type=int, default=262144, help="stream mode: input samples per block")
+    ap.add_argument("--block", type=int, default=0,
+                    help="stream mode: input samples per block (default: stream.tile_filling_block(2^18, chunk, taps) = 261 120 - "
+                         "the window [halo | block] + L - 1 outputs then fills 32 tiles of the FIR kernel; 2^18 itself spills 639 "
+                         "samples into a 33rd)")
     ap.add_argument("--regen", action="store_true", help="stream mode: draw a fresh random block inside every timed step")
     ap.add_argument("--cpu-sources-per-core", type=int, default=16)
     ap.add_argument("--lib", default=None, help="another build of the ABI to route every call through (diagnostic / stamps "
@@ -271,7 +274,8 @@ def stream_mode(args):
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", world_size=1, rank=0, device_id=dev)
-    n_total, k, s, l, fs, B = args.sources, args.chunk, args.subchunk, args.taps, args.fs, args.block
+    n_total, k, s, l, fs = args.sources, args.chunk, args.subchunk, args.taps, args.fs
+    B = args.block if args.block > 0 else bas.stream.tile_filling_block(1 << 18, k, l)
     host = bas.synth.make_table("consistent", 0).truncated(l)
     tbl = bas.irs_and_delaydiffs(host.upsampling, host.diffs_left, host.diffs_right, host.irs_left, host.irs_right,
                                  device=dev)

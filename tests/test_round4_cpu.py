@@ -139,3 +139,19 @@ def test_generated_unit_blocks_compute_the_fir(lseg, nsub, nbuf, psplit):
     if not psplit and nsub == 1:                             # round 3's block (two x buffers) through the same interpreter
         y0, want0 = emu.run(gen.gen_unit(261, lseg), 261, lseg, 1, False, seed=lseg + 7 * nsub)
         assert np.abs(y0 - want0).max() <= 1e-12 * np.abs(want0).max() and np.array_equal(want0, want)
+
+
+def test_tile_filling_block():
+    """stream.tile_filling_block: a multiple of the chunk size, not above the request, whose window [halo | block] + L - 1
+    outputs does not spill into one more 8192-output tile; small requests come back rounded to chunks."""
+    f = bas.stream.tile_filling_block
+    assert f(1 << 18, 512, 128) == 261120                   # 2^18 would be 32.08 tiles
+    for about, k, l in [(1 << 18, 512, 128), (1 << 20, 512, 128), (32768, 512, 100), (9000, 512, 128), (1 << 18, 1024, 128),
+                        (100000, 512, 300)]:
+        b = f(about, k, l)
+        halo = -(-(l - 1) // k) * k
+        assert b % k == 0 and 0 < b <= about
+        t_out = halo + b + l - 1
+        assert -(-t_out // 8192) == t_out // 8192 or t_out % 8192 > 8192 - k    # ends within a chunk of a tile boundary
+        assert t_out // 8192 == (halo + about + l - 1) // 8192 or -(-t_out // 8192) == (halo + about + l - 1) // 8192
+    assert f(512, 512, 128) == 512 and f(300, 128, 128) == 256 and f(100, 512, 128) == 512

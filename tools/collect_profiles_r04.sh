@@ -64,8 +64,8 @@ fi
 
 if has stream; then
   # 5. streaming: config 5 - the WHOLE hour, kernel stats of 40 blocks, the collective path on one rank, real-time sized blocks
-  $B --mode stream --sources 1024 --fs 48000 --steps 659 --warmup 3 > $O/stream_hour.json 2> $O/stream.err
-  $B --mode stream --sources 1024 --fs 48000 --steps 659 --warmup 3 --regen > $O/stream_hour_regen.json 2>> $O/stream.err
+  $B --mode stream --sources 1024 --fs 48000 --steps 662 --warmup 3 > $O/stream_hour.json 2> $O/stream.err
+  $B --mode stream --sources 1024 --fs 48000 --steps 662 --warmup 3 --regen > $O/stream_hour_regen.json 2>> $O/stream.err
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stream -o bench -- python3 bench.py --no-traffic --mode stream --sources 1024 --fs 48000 --steps 40 --warmup 3 > /dev/null 2>> $O/stream.err
   $B --mode stream --sources 1024 --fs 48000 --steps 100 --warmup 3 --force-pg > $O/stream_forcepg.json 2>> $O/stream.err
   python3 tools/stream_host_time.py 256 512 2>/dev/null > $O/stream_host_time.txt
