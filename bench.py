@@ -245,7 +245,7 @@ class HipEvents:
 def stream_mode(args):
     """BASELINE config 5 (1024 sources, 48 kHz, hours of audio): `steps` blocks of `block` samples through
     StreamRenderer; nothing but one block of inputs, chunk IRs and outputs is ever resident, and the
-    trajectory -> parameter step runs on the device.  `--steps 659` is the whole hour at 48 kHz.  With --gpus N
+    trajectory -> parameter step runs on the device.  `--steps 662` is the whole hour at 48 kHz (blocks of 261 120 samples).  With --gpus N
     (torch.distributed.run) the sources are sharded over the ranks and every block ends in one gather of the
     partial stereo block (distributed.ShardedStreamRenderer); --force-pg runs that path on one rank with a real RCCL
     communicator.  One JSON line, not the contract's metric."""
