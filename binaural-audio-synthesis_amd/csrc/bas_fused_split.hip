@@ -41,8 +41,9 @@ __device__ unsigned long long bas_fs_stamps[1024 * 8 * 8];
 #endif
 
 #if FZ_ASM
-// UNITLEN = 128 / 104: every unit is one whole segment of that many taps (L = 121 .. 128; L = 97 .. 104 - the reference's
-// default samples_to_keep is 100, apply_hrtf.py:595) and its five row steps run as ONE assembly block; 0: per-step blocks.
+// UNITLEN = 128 / 104: every (unit, segment) pass is one whole segment of that many taps (L = 121 .. 128 and the lengths of
+// several whole 128-tap segments, 249 .. 256, .., 505 .. 512; L = 97 .. 104 - the reference's default samples_to_keep is
+// 100, apply_hrtf.py:595) and its five row steps run as ONE assembly block; 0: per-step blocks.
 // (A template parameter, not a branch: with both assembly statements in one loop the compiler keeps the accumulators
 // elsewhere and copies all 98 into and out of the pinned registers around every block.)
 // NSUB = 2 / 4: subchunks of 16 / 8 samples (the reference accepts any divisor of the chunk, apply_hrtf.py:401-402): a row
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
         // instructions, six of them quarter-rate integer multiplies, that round 4's first builds issued in front of every
         // unit - 3 % of a unit's vector instructions) and kept as LDS addresses; per unit they move to the other buffer in
         // place (six adds).  The block's operands live in registers across it anyway.
-        long addr_tile = -1;
+        long addr_tile = -1;                                 // (tile, segment) the addresses below belong to: tile * nseg + segment
         int addr_buf = 0;                                    // the LDS buffer the addresses below point into
         unsigned tapv[5] = {0u, 0u, 0u, 0u, 0u}, xrow4 = 0u;
         float alv[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, blv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -235,15 +236,16 @@ __global__ __launch_bounds__(512, 1) void bas_render_fs_kernel(
             };
             if constexpr (UNITLEN != 0) {
                 const int cur_buf = (int)(pid & 1);
-                if (tile == addr_tile && cur_buf != addr_buf) {              // (uniform) same rows, the other buffer: in place
+                const long akey = tile * nseg + sg;                          // (IRs of several segments: the window moves with the segment)
+                if (akey == addr_tile && cur_buf != addr_buf) {              // (uniform) same rows, the other buffer: in place
                     const unsigned delta = cur_buf ? buf_bytes : 0u - buf_bytes;
 #pragma unroll
                     for (int r = 0; r < 5; ++r) tapv[r] += delta;
                     xrow4 += delta;
                     addr_buf = cur_buf;
                 }
-                if (tile != addr_tile) {                     // (uniform; one tap segment per unit: the window depends on the tile alone)
-                    addr_tile = tile;
+                if (akey != addr_tile) {                     // (uniform; with one tap segment per unit the window depends on the tile alone)
+                    addr_tile = akey;
                     addr_buf = cur_buf;
                     const unsigned bufb = (unsigned)reinterpret_cast<uintptr_t>(lds4 + cur_buf * buf4);
                     const int row_out = 64 * wv + lane + G.halo;             // window row holding the lane's outputs
@@ -540,8 +542,10 @@ extern "C" int bas_debug_read_fs_stamps(unsigned long long *host, size_t count) 
 
 #endif  // FZ_ASM
 
-int bas_fs_unit_len(int Lp) {                               // segment lengths bas_fir_asm.inc holds a unit block for
-    return FS_UNIT_BLOCK && (Lp == 128 || Lp == 104) ? Lp : 0;
+int bas_fs_unit_len(int Lp) {                               // segment lengths bas_fir_asm.inc holds a unit block for:
+    // 104 taps; 128 taps - and IRs of SEVERAL whole 128-tap segments (L = 249 .. 256, 377 .. 384, 505 .. 512 - the default
+    // samples_to_keep of the reference's loader, apply_hrtf.py:23 - ...): every (unit, segment) pass is one unit block
+    return FS_UNIT_BLOCK && (Lp == 104 || (Lp > 0 && Lp % 128 == 0)) ? (Lp == 104 ? 104 : 128) : 0;
 }
 
 size_t bas_fs_lds_bytes(int nslots) {

@@ -215,8 +215,9 @@ int bas_interp2d_plan_angles_f32(const double *diffs, const double *elev, const 
 int bas_render_fused_supported(int n_src, long T_in, int K, int S, int L);
 /* Name of the kernel bas_render_mix_fused_f32 launches for these operands, for profiling tools ("" when the sizes are
  * not served): "bas_render_fs_kernel<128>" / "<104>" / "<0>" - one workgroup of four filter and four stager waves per
- * CU, two LDS buffers (scenes with more than one (tile of 8192, source) unit per CU; <128>: L = 121 .. 128, <104>:
- * L = 97 .. 104: a unit's five row steps as one assembly block; "<128,2>" / "<104,2>", "<128,4>" / "<104,4>": the same
+ * CU, two LDS buffers (scenes with more than one (tile of 8192, source) unit per CU; <128>: L = 121 .. 128 and the lengths of
+ * several whole 128-tap segments - 249 .. 256, 377 .. 384, 505 .. 512, .. -, <104>: L = 97 .. 104: the five row steps of
+ * a (unit, segment) pass as one assembly block; "<128,2>" / "<104,2>", "<128,4>" / "<104,4>": the same
  * for subchunks of 16 / 8 samples - two / four crossfaded tap sets per row of 32 inputs); "bas_render_fq_kernel" - four waves per tile of 2048
  * outputs, staging and row steps dealt over them (small scenes: one source, a handful, real-time blocks) - or
  * "bas_render_fz_kernel<4,0>" / "<1,0>" / "<4,1>": every wave stages and filters (two workgroups of four waves per CU on

@@ -433,3 +433,38 @@ def test_ring_search_at_and_around_every_node(branch):
     assert np.array_equal(idx_d.cpu().numpy().reshape(idx_h.shape), idx_h)
     assert np.array_equal(w_d.cpu().numpy().reshape(w_h.shape), w_h)
     assert e.size > 5000
+
+
+@pytest.mark.parametrize("l", [256, 250, 384, 512])
+def test_unit_blocks_for_irs_of_several_segments(l):
+    """IR lengths of several whole 128-tap segments (L = 249..256, 377..384, 505..512 - 512 is the default samples_to_keep
+    of the reference's loader, apply_hrtf.py:23): every (unit, segment) pass of the split-role kernel is one unit block
+    (round 4 until late: the per-step blocks, 4-8 % slower).  The shipped library on a big scene against the stored-IR path
+    and oracle windows; subchunks of 16 stay on the stored-IR path for these lengths."""
+    lib = bas._hip.lib()
+    assert os.path.basename(lib._name) == "libbas_hip.so"
+    n_src, n, k, s = 40, 100000, 512, 32
+    h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, 0.5 / n_src)
+    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() == "bas_render_fs_kernel<128>"
+    assert lib.bas_render_fused_kernel_name(256, 441344, 512, 32, l).decode() == "bas_render_fs_kernel<128>"
+    assert lib.bas_render_fused_supported(n_src, in_length, k, 16, l) == 0
+    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l - 16).decode() == "bas_render_fs_kernel<0>"   # (a short last segment)
+    d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
+    got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none").cpu().numpy()
+    stored = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=False).cpu().numpy()
+    assert rel_err(got, stored) <= 5e-6, rel_err(got, stored)
+    scale = np.abs(got).max()
+    worst = 0.0
+    for n0, n1 in [(0, 40), (8192 - 20, 8192 + 20), (100 * k - 8, 100 * k + 24), (in_length + l - 1 - 40, in_length + l - 1)]:
+        m0, m1 = max(n0 - l + 1, 0), min(n1, n)
+        want = np.zeros((2, n1 - n0))
+        for i in range(n_src):
+            cache = {}
+
+            def ir_of(c, i=i, cache=cache):
+                if c not in cache:
+                    cache[c] = orc.interp2d(h, elev[i, c], azim[i, c])
+                return cache[c]
+            want += orc.render_window(sigs[i, m0:m1].astype(np.float64), m0, k, s, ir_of, l, n0, n1)
+        worst = max(worst, float(np.abs(got[n0:n1].T - want).max()) / scale)
+    assert worst <= REL, worst
