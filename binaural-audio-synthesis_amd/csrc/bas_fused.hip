@@ -643,8 +643,9 @@ static FzPlan fz_plan(int n_src, long T_in, int K, int S, int L) {
 static FzPlan fz_plan_uncached(int n_src, long T_in, int K, int S, int L) {
     FzPlan p = {};
     // subchunks: multiples of 32 (a row of 32 inputs meets one crossfaded tap set), or 16 / 8 - two / four sets per row, which only the
-    // unit blocks of the split-role kernel hold (scenes with more than one (tile of 8192, source) unit per CU, L = 97 .. 104 or 121 .. 128)
-    const bool s16 = (S == 16 || S == 8) && FZ_SPLIT && L <= 128 && bas_fs_unit_len((L + 7) & ~7) != 0;    // (8: four sets per row; one segment)
+    // unit blocks of the split-role kernel hold (scenes with more than one (tile of 8192, source) unit per CU; L = 97 .. 104, 121 .. 128,
+    // or several whole 128-tap segments: bas_fs_unit_len)
+    const bool s16 = (S == 16 || S == 8) && FZ_SPLIT && bas_fs_unit_len((L + 7) & ~7) != 0;    // (8: four sets per row)
     if (n_src <= 0 || T_in <= 0 || K < 32 || K % 32 != 0 || (S % 32 != 0 && !s16) || K % S != 0 || L <= 0) return p;
     const long T_out = T_in + L - 1;
     const int cus = bas_device_cus();

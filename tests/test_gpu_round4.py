@@ -435,20 +435,21 @@ def test_ring_search_at_and_around_every_node(branch):
     assert e.size > 5000
 
 
-@pytest.mark.parametrize("l", [256, 250, 384, 512])
-def test_unit_blocks_for_irs_of_several_segments(l):
+@pytest.mark.parametrize("l,s", [(256, 32), (250, 32), (384, 32), (512, 32), (256, 16), (505, 8)])
+def test_unit_blocks_for_irs_of_several_segments(l, s):
     """IR lengths of several whole 128-tap segments (L = 249..256, 377..384, 505..512 - 512 is the default samples_to_keep
     of the reference's loader, apply_hrtf.py:23): every (unit, segment) pass of the split-role kernel is one unit block
     (round 4 until late: the per-step blocks, 4-8 % slower).  The shipped library on a big scene against the stored-IR path
-    and oracle windows; subchunks of 16 stay on the stored-IR path for these lengths."""
+    and oracle windows; subchunks of 16 / 8 (two / four tap sets per row) likewise."""
     lib = bas._hip.lib()
     assert os.path.basename(lib._name) == "libbas_hip.so"
-    n_src, n, k, s = 40, 100000, 512, 32
+    n_src, n, k = 40, 100000, 512
     h, sigs, elev, azim, in_length = _scene(l, n_src, n, k, 0.5 / n_src)
-    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() == "bas_render_fs_kernel<128>"
-    assert lib.bas_render_fused_kernel_name(256, 441344, 512, 32, l).decode() == "bas_render_fs_kernel<128>"
-    assert lib.bas_render_fused_supported(n_src, in_length, k, 16, l) == 0
-    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l - 16).decode() == "bas_render_fs_kernel<0>"   # (a short last segment)
+    want_name = "bas_render_fs_kernel<128>" if s == 32 else f"bas_render_fs_kernel<128,{32 // s}>"
+    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, s, l).decode() == want_name
+    assert lib.bas_render_fused_kernel_name(256, 441344, 512, s, l).decode() == want_name
+    assert lib.bas_render_fused_kernel_name(n_src, in_length, k, 32, l - 16).decode() == "bas_render_fs_kernel<0>"   # (a short last segment)
+    assert lib.bas_render_fused_supported(n_src, in_length, k, 16, l - 16) == 0                                      # (and no second tap set there)
     d = bas.irs_and_delaydiffs(h.upsampling, h.diffs_left, h.diffs_right, h.irs_left, h.irs_right)
     got = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none").cpu().numpy()
     stored = bas.render_sources(sigs, k, s, elev, azim, d, normalize="none", fused=False).cpu().numpy()
