@@ -260,7 +260,9 @@ def test_bench_line_round3_fields():
                        timeout=600, env=_clean_env(BAS_BENCH_MAX_CORES="2"), cwd=_root())
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")][0])
-    assert d["cold"]["ms_per_step"] > 0 and d["graph"] == "plain launches"
+    # (a scene this small runs the four-wave kernel: `--graph auto` replays its three launches as one hipGraph and times
+    # the FIR kernel in eager steps behind the timed region; the headline scene stays plain launches: test_gpu_parity's bench tests)
+    assert d["cold"]["ms_per_step"] > 0 and d["graph"].startswith("render step replayed as one hipGraph") and d["roofline"]["kernel_ms"] > 0
     assert 0 < d["valu"]["frac_executed"] < d["valu"]["frac"] < 1
     assert d["self_check_rel_err"] <= 1e-5 and "multi_gpu_status" in d
     assert d["cpu_baseline"]["cores"] == 2 and d["roofline"]["bound"] == "hbm"
