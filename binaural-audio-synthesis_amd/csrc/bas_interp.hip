@@ -258,8 +258,10 @@ struct PlanAngles {
     RingTable R;
 };
 
+#define BAS_PLAN_WAVE_STAGED_FROM 32768   // queries from which the plan kernel stages its records per wave (see its end)
+
 // plan kernel: one thread per (query, ear)
-template <int ANG>
+template <int ANG, int WAVE_STAGED = 0>
 __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__restrict__ diffs,
                                                                   const int32_t *__restrict__ idx,
                                                                   const double *__restrict__ w, int n,
@@ -369,21 +371,68 @@ __global__ __launch_bounds__(256) void bas_interp2d_plan_kernel(const double *__
     }
     // 144-byte records written lane by lane would touch every 64-byte segment two or three times: the block's records go
     // through LDS (stride 37 words: conflict-free) and leave as one contiguous run of 16-byte stores
-    __shared__ unsigned stage[256 * (BAS_PLANS_WORDS + 1)];
-    {
-        const unsigned *src = reinterpret_cast<const unsigned *>(&ps);
-        unsigned *row = stage + threadIdx.x * (BAS_PLANS_WORDS + 1);
+    // 144-byte records written lane by lane would touch every 64-byte segment two or three times: they go through LDS
+    // (stride 37 words: conflict-free) and leave as contiguous runs of 16-byte stores.
+    // WAVE_STAGED = 0 (small batches, where one wave's chain of dependent round trips IS the kernel's time): the block's
+    // 256 records in one staging area (37.9 KB: three workgroups per CU), one barrier.
+    // WAVE_STAGED = 1 (large batches): the staging area sets how many workgroups a CU holds, and a kernel made of such
+    // chains wants all the waves its 63 registers allow - each WAVE stages its 64 records in two passes through a region
+    // of its own and writes them out itself (its records are one contiguous run of the output; no workgroup barrier):
+    // 18.9 KB per workgroup, six per CU: 21.2 -> 18.3 us for 221 k queries (four passes, eight per CU: the same; for a
+    // single source's 863 queries the passes lengthen the chain: 6.2 -> 7.6 us, which is why both forms exist).
+    if constexpr (WAVE_STAGED == 0) {
+        __shared__ unsigned stage[256 * (BAS_PLANS_WORDS + 1)];
+        {
+            const unsigned *src = reinterpret_cast<const unsigned *>(&ps);
+            unsigned *row = stage + threadIdx.x * (BAS_PLANS_WORDS + 1);
 #pragma unroll
-        for (int i = 0; i < BAS_PLANS_WORDS; ++i) row[i] = src[i];
+            for (int i = 0; i < BAS_PLANS_WORDS; ++i) row[i] = src[i];
+        }
+        __syncthreads();
+        const long t0 = blockIdx.x * 256L;
+        const long live = 2L * n - t0 < 256 ? 2L * n - t0 : 256;            // records of this block
+        u32x4 *dst = reinterpret_cast<u32x4 *>(plans + t0);
+        for (int i = threadIdx.x; i < live * (BAS_PLANS_WORDS / 4); i += 256) {
+            const int r = i / (BAS_PLANS_WORDS / 4), c = i - r * (BAS_PLANS_WORDS / 4);
+            const unsigned *q = stage + r * (BAS_PLANS_WORDS + 1) + 4 * c;
+            dst[i] = u32x4{q[0], q[1], q[2], q[3]};
+        }
+        return;
     }
-    __syncthreads();
-    const long t0 = blockIdx.x * 256L;
-    const long live = 2L * n - t0 < 256 ? 2L * n - t0 : 256;            // records of this block
-    u32x4 *dst = reinterpret_cast<u32x4 *>(plans + t0);
-    for (int i = threadIdx.x; i < live * (BAS_PLANS_WORDS / 4); i += 256) {
-        const int r = i / (BAS_PLANS_WORDS / 4), c = i - r * (BAS_PLANS_WORDS / 4);
-        const unsigned *q = stage + r * (BAS_PLANS_WORDS + 1) + 4 * c;
-        dst[i] = u32x4{q[0], q[1], q[2], q[3]};
+    constexpr int PLAN_PASSES = 2, PER_PASS = 64 / PLAN_PASSES, Q = BAS_PLANS_WORDS / 4;
+    __shared__ unsigned wstage[4 * PER_PASS * (BAS_PLANS_WORDS + 1)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned *region = wstage + wave * PER_PASS * (BAS_PLANS_WORDS + 1);
+    const long w0 = blockIdx.x * 256L + 64L * wave;                      // first record of this wave
+    long live_w = 2L * n - w0;                                           // records of this wave that exist
+    live_w = live_w < 0 ? 0 : (live_w > 64 ? 64 : live_w);
+    unsigned rec[BAS_PLANS_WORDS];                                       // the record as words (EarPlanS: off, w, o4), all in registers
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        rec[i] = ps.off[i];
+        rec[16 + i] = __float_as_uint(ps.w[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rec[32 + i] = ps.o4[i];
+#pragma unroll
+    for (int pass = 0; pass < PLAN_PASSES; ++pass) {
+        if (lane / PER_PASS == pass) {
+            unsigned *row = region + (lane - pass * PER_PASS) * (BAS_PLANS_WORDS + 1);
+#pragma unroll
+            for (int i = 0; i < BAS_PLANS_WORDS; ++i) row[i] = rec[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // (a wave's LDS accesses are in order; the compiler must keep them so)
+        __builtin_amdgcn_wave_barrier();
+        long live_p = live_w - pass * PER_PASS;                          // records of this pass that exist
+        live_p = live_p < 0 ? 0 : (live_p > PER_PASS ? PER_PASS : live_p);
+        u32x4 *dst = reinterpret_cast<u32x4 *>(plans + w0 + pass * PER_PASS);
+        for (int i = lane; i < live_p * Q; i += 64) {
+            const int r = i / Q, c = i - r * Q;
+            const unsigned *q = region + r * (BAS_PLANS_WORDS + 1) + 4 * c;
+            dst[i] = u32x4{q[0], q[1], q[2], q[3]};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -501,8 +550,12 @@ extern "C" int bas_interp2d_plan_f32(const double *diffs, const int32_t *idx, co
                 BAS_E_WORKSPACE, "bas_interp2d_plan_f32: 16-byte aligned buffer of %zu bytes needed, %zu given",
                 bas_interp2d_workspace_bytes(n), plans_bytes);
     const long rows = 2L * n;
-    hipLaunchKernelGGL(bas_interp2d_plan_kernel<0>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                       bas_stream(stream), diffs, idx, w, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PlanAngles{});
+    if (n >= BAS_PLAN_WAVE_STAGED_FROM)
+        hipLaunchKernelGGL((bas_interp2d_plan_kernel<0, 1>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                           bas_stream(stream), diffs, idx, w, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PlanAngles{});
+    else
+        hipLaunchKernelGGL((bas_interp2d_plan_kernel<0, 0>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
+                           bas_stream(stream), diffs, idx, w, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PlanAngles{});
     return bas_check_launch("bas_interp2d_plan_f32");
 }
 
@@ -532,12 +585,12 @@ extern "C" int bas_interp2d_plan_angles_f32(const double *diffs, const double *e
                     BAS_E_SHAPE, "bas_interp2d_plan_angles_f32: ring %d out of the %d-direction table", i, ndir);
     }
     const long rows = 2L * n;
-    if (branch == BAS_BRANCH_PYFLOAT)
-        hipLaunchKernelGGL(bas_interp2d_plan_kernel<2>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                           bas_stream(stream), diffs, nullptr, nullptr, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PA);
-    else
-        hipLaunchKernelGGL(bas_interp2d_plan_kernel<1>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0,
-                           bas_stream(stream), diffs, nullptr, nullptr, n, ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PA);
+    typedef void (*plan_fn)(const double *, const int32_t *, const double *, int, int, int, int, EarPlanS *, PlanAngles);
+    const bool big = n >= BAS_PLAN_WAVE_STAGED_FROM;
+    const plan_fn fn = branch == BAS_BRANCH_PYFLOAT ? (big ? bas_interp2d_plan_kernel<2, 1> : bas_interp2d_plan_kernel<2, 0>)
+                                                    : (big ? bas_interp2d_plan_kernel<1, 1> : bas_interp2d_plan_kernel<1, 0>);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, bas_stream(stream), diffs, nullptr, nullptr, n,
+                       ndir, L, U, reinterpret_cast<EarPlanS *>(plans), PA);
     return bas_check_launch("bas_interp2d_plan_angles_f32");
 }
 
@@ -562,8 +615,12 @@ extern "C" int bas_interp2d_f32(const float *packed, const double *diffs, const 
                            w, (long)n, ndir, L, U, H);
         return bas_check_launch("bas_interp2d_f32(generic)");
     }
-    hipLaunchKernelGGL(bas_interp2d_plan_kernel<0>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
-                       w, n, ndir, L, U, plans, PlanAngles{});
+    if (n >= BAS_PLAN_WAVE_STAGED_FROM)
+        hipLaunchKernelGGL((bas_interp2d_plan_kernel<0, 1>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
+                           w, n, ndir, L, U, plans, PlanAngles{});
+    else
+        hipLaunchKernelGGL((bas_interp2d_plan_kernel<0, 0>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, diffs, idx,
+                           w, n, ndir, L, U, plans, PlanAngles{});
     int rc = bas_check_launch("bas_interp2d_f32(plan)");
     if (rc) return rc;
     long blocks = ((long)n + 3) / 4;
