@@ -5,6 +5,7 @@
  *   cabi_check fused [scale]    the DEFAULT path of the Python layer, from C: bas_table_pack_f32 ->
  *                               bas_traj_params_branch_f64 -> bas_interp2d_plan_f32 -> bas_render_mix_fused_f32 (peak rule
  *                               in the kernel tail) -> bas_render_status, on a scene the plan gives the split-role kernel;
+ *                               then the same window as one block of a stream (bas_render_stream_block_f32);
  *                               the checker is fed the chunk IRs of bas_interp2d_f32 (itself pinned to the reference's
  *                               goldens by the Python tests)
  * Exit code 0 = parity within 1e-5 norm-relative. */
@@ -139,9 +140,55 @@ static int check_default_path(double scale) {
         }
     printf("cabi_check fused: kernel %s, peak before the rule %.4f, status %d, rel err %.3e\n",
            bas_render_fused_kernel_name(N_SRC, T_in, K, S, L), peak, status, err / ref);
+    /* ---- the same window as ONE BLOCK OF A STREAM (bas_render_stream_block_f32): halo = one chunk, the block = the rest.
+     * Its output must be the un-normalised render bit for bit; the carried state must have moved as bas.h says. */
+    int stream_ok = 1;
+    {
+        const int halo = K, nh = 1, nb = n_q - 1;
+        const long B = T_in - halo;
+        float *d_x2, *d_y2, *d_y3, *d_rpeak;
+        double *d_e2, *d_a2, *d_last;
+        CHECK_HIP(hipMalloc((void **)&d_x2, sizeof(float) * N_SRC * T_in));
+        CHECK_HIP(hipMalloc((void **)&d_y2, sizeof(float) * 2 * T_out));
+        CHECK_HIP(hipMalloc((void **)&d_y3, sizeof(float) * 2 * T_out));
+        CHECK_HIP(hipMalloc((void **)&d_rpeak, sizeof(float)));
+        CHECK_HIP(hipMalloc((void **)&d_e2, sizeof(double) * n_query));
+        CHECK_HIP(hipMalloc((void **)&d_a2, sizeof(double) * n_query));
+        CHECK_HIP(hipMalloc((void **)&d_last, sizeof(double) * 2 * N_SRC));
+        CHECK_HIP(hipMemcpy(d_x2, d_x, sizeof(float) * N_SRC * T_in, hipMemcpyDeviceToDevice));
+        CHECK_HIP(hipMemcpy(d_e2, d_elev, sizeof(double) * n_query, hipMemcpyDeviceToDevice));
+        CHECK_HIP(hipMemcpy(d_a2, d_azim, sizeof(double) * n_query, hipMemcpyDeviceToDevice));
+        CHECK_HIP(hipMemset(d_rpeak, 0, sizeof(float)));
+        CHECK_BAS(bas_render_mix_fused_f32(d_x, T_in, d_packed, d_plans, N_SRC, T_in, K, S, L, U, NDIR, d_y3, 0, NULL, 0, d_ws,
+                                           ws_bytes, NULL));
+        CHECK_BAS(bas_render_stream_block_f32(d_x2, T_in, d_packed, d_plans, N_SRC, T_in, K, S, L, U, NDIR, d_y2, d_ws, ws_bytes,
+                                              halo, d_e2, d_a2, n_q, nh, nb, d_last, d_rpeak, NULL));
+        CHECK_HIP(hipDeviceSynchronize());
+        float *y2 = (float *)malloc(sizeof(float) * 2 * T_out), *y3 = (float *)malloc(sizeof(float) * 2 * T_out);
+        float *x2 = (float *)malloc(sizeof(float) * N_SRC * T_in), rpeak = -1.f;
+        double *e2 = (double *)malloc(sizeof(double) * n_query), *last = (double *)malloc(sizeof(double) * 2 * N_SRC);
+        CHECK_HIP(hipMemcpy(y2, d_y2, sizeof(float) * 2 * T_out, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(y3, d_y3, sizeof(float) * 2 * T_out, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(x2, d_x2, sizeof(float) * N_SRC * T_in, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(e2, d_e2, sizeof(double) * n_query, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(last, d_last, sizeof(double) * 2 * N_SRC, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(&rpeak, d_rpeak, sizeof(float), hipMemcpyDeviceToHost));
+        float emitted = 0.f;
+        for (long i = 0; i < 2 * T_out; ++i) stream_ok &= y2[i] == y3[i];
+        for (int e = 0; e < 2; ++e)
+            for (long i = halo; i < halo + B; ++i) emitted = fmaxf(emitted, fabsf(y3[e * T_out + i]));
+        stream_ok &= rpeak == emitted;
+        for (int s = 0; s < N_SRC; ++s) {
+            for (long i = 0; i < halo; ++i) stream_ok &= x2[s * T_in + i] == x32[s * T_in + B + i];
+            stream_ok &= last[s] == elev[(long)s * n_q + n_q - 1] && last[N_SRC + s] == azim[(long)s * n_q + n_q - 1];
+            stream_ok &= e2[(long)s * n_q] == elev[(long)s * n_q + nb - 1];
+        }
+        printf("cabi_check fused: the window as one stream block: %s (running peak %.4f)\n", stream_ok ? "ok" : "MISMATCH", rpeak);
+        hipFree(d_x2); hipFree(d_y2); hipFree(d_y3); hipFree(d_rpeak); hipFree(d_e2); hipFree(d_a2); hipFree(d_last);
+    }
     hipFree(d_irs); hipFree(d_packed); hipFree(d_diffs); hipFree(d_node); hipFree(d_elev); hipFree(d_azim); hipFree(d_idx);
     hipFree(d_w); hipFree(d_plans); hipFree(d_wsH); hipFree(d_ws); hipFree(d_x); hipFree(d_y); hipFree(d_peak); hipFree(d_H);
-    return (err / ref <= 1e-5 && status == 0) ? 0 : 1;
+    return (err / ref <= 1e-5 && status == 0 && stream_ok) ? 0 : 1;
 }
 
 int main(int argc, char **argv) {
