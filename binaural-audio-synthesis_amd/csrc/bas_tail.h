@@ -36,8 +36,11 @@ struct BasTail {
     int normalize;              // apply the rule
 };
 
+// (s_nop 1: a store of more than 8 bytes reads its data registers up to two wait states after it issues, gfx940+; for its
+// own stores the compiler inserts that distance before any instruction that overwrites them - for an asm statement it
+// cannot know to.  Without it `v_max_f32 v3, |v3|, |v3|` right behind the store put |y| into memory for a few lanes.)
 __device__ __forceinline__ void bas_store4_sc1(float *p, f32x4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void bas_store1_sc1(float *p, float v) {
     asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");

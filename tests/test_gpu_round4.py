@@ -469,3 +469,33 @@ def test_unit_blocks_for_irs_of_several_segments(l, s):
             want += orc.render_window(sigs[i, m0:m1].astype(np.float64), m0, k, s, ir_of, l, n0, n1)
         worst = max(worst, float(np.abs(got[n0:n1].T - want).max()) / scale)
     assert worst <= REL, worst
+
+
+def test_mix_finish_of_unaligned_parts_many_times():
+    """Eight gathered parts of 2 x 441 471 floats (every second one 8 bytes off a 16-byte boundary: the headline scene's
+    mix) summed with 16-byte loads and stored by the inline-assembly sc1 store, 50 launches, rule firing and not: every one
+    equals sum + scale bit for bit.  (The store reads its data registers up to two wait states after it issues; without the
+    s_nop behind it the |y| of the peak search, computed in place, reached memory for a few lanes in one launch of seven.)"""
+    import torch
+    _hip = bas._hip
+    n_parts, n = 8, 2 * 441471
+    gen = torch.Generator(device="cuda").manual_seed(77)
+    stride = n + 3
+    parts = torch.rand((n_parts, stride), generator=gen, device="cuda") - 0.5
+    st = _hip.current_stream(parts.device)
+    want = torch.empty((n,), dtype=torch.float32, device="cuda")
+    pk0 = torch.empty((1,), dtype=torch.float32, device="cuda")
+    _hip.call("bas_mix_partials_f32", _hip.ptr(parts), n_parts, stride, n, _hip.ptr(want), _hip.ptr(pk0), st)
+    raw = want.clone()
+    _hip.call("bas_scale_by_peak_f32", _hip.ptr(want), n, _hip.ptr(pk0), st)
+    assert float(pk0) > 1.0
+    ws = _hip.new_workspace(_hip.lib().bas_mix_workspace_bytes(), "cuda")
+    got = torch.empty((n,), dtype=torch.float32, device="cuda")
+    pk = torch.empty((1,), dtype=torch.float32, device="cuda")
+    for it in range(50):
+        normalize = it & 1
+        got.fill_(5.0)
+        _hip.call("bas_mix_finish_f32", _hip.ptr(parts), n_parts, stride, n, _hip.ptr(got), _hip.ptr(pk), normalize,
+                  _hip.ptr(ws), ws.numel(), st)
+        assert torch.equal(got, want if normalize else raw), (it, int((got != (want if normalize else raw)).sum()))
+        assert float(pk) == float(pk0)
